@@ -1,0 +1,94 @@
+"""libfm loader with the reference's surface (drop-in for /root/reference/LoadData.py:15-112).
+
+Same constructor, same attributes (``features``, ``features_M``, ``Train_data``, ``Validation_data``,
+``Test_data`` as ``{'X': list of id lists, 'Y': list of floats}``), same console prints, same quirks:
+
+* the dictionary key is the WHOLE token ``"idx:val"``; the value part is never used as a number
+  (LoadData.py:49-53, :99);
+* ids are handed out in first-appearance order over train, then TEST, then validation
+  (LoadData.py:35-39);
+* ``features_M`` is the number of distinct tokens, not max-id+1 (LoadData.py:42);
+* rows are re-ordered by ``np.argsort`` of their length (LoadData.py:109; not a stable sort, so the
+  order among equal-length rows is whatever numpy gives - parity is on the multiset of rows);
+* ``log_loss`` maps labels to {0,1} with ``> 0`` (LoadData.py:93-97).
+
+Unlike the reference each file is tokenised once (the reference reads every file twice), and
+``packed()`` hands the splits out as dense int32/float32 arrays for the device-resident pipeline.
+"""
+import numpy as np
+
+
+class LoadData(object):
+    # Three files are needed in the path: <path><dataset>/<dataset>.{train,test,validation}.libfm
+    def __init__(self, path, dataset, loss_type):
+        self.path = path + dataset + "/"
+        self.trainfile = self.path + dataset + ".train.libfm"
+        self.testfile = self.path + dataset + ".test.libfm"
+        self.validationfile = self.path + dataset + ".validation.libfm"
+        self._rows = {}
+        self.features_M = self.map_features()
+        self.Train_data, self.Validation_data, self.Test_data = self.construct_data(loss_type)
+
+    # -- token -> dense id ---------------------------------------------------------------------
+    def map_features(self):
+        self.features = {}
+        for fname in (self.trainfile, self.testfile, self.validationfile):
+            self.read_features(fname)
+            print(len(self.features))
+        return len(self.features)
+
+    def read_features(self, file):
+        feats = self.features
+        labels, rows = [], []
+        with open(file) as fh:
+            for line in fh:
+                items = line.strip().split(' ')
+                ids = []
+                for tok in items[1:]:
+                    fid = feats.get(tok)
+                    if fid is None:
+                        fid = len(feats)
+                        feats[tok] = fid
+                    ids.append(fid)
+                labels.append(items[0])
+                rows.append(ids)
+        self._rows[file] = (labels, rows)
+
+    # -- splits ----------------------------------------------------------------------------------
+    def construct_data(self, loss_type):
+        out = []
+        for fname, title in ((self.trainfile, "# of training:"),
+                             (self.validationfile, "# of validation:"),
+                             (self.testfile, "# of test:")):
+            X_, Y_, Y_for_logloss = self.read_data(fname)
+            out.append(self.construct_dataset(X_, Y_for_logloss if loss_type == 'log_loss' else Y_))
+            print(title, len(Y_))
+        return tuple(out)
+
+    def read_data(self, file):
+        if file not in self._rows:
+            self.read_features(file)
+        labels, rows = self._rows[file]
+        Y_ = [1.0 * float(t) for t in labels]
+        Y_for_logloss = [1.0 if v > 0 else 0.0 for v in Y_]
+        return rows, Y_, Y_for_logloss
+
+    def construct_dataset(self, X_, Y_):
+        order = np.argsort([len(r) for r in X_])
+        return {'Y': [Y_[i] for i in order], 'X': [X_[i] for i in order]}
+
+    def truncate_features(self):
+        """Cut every row to the shortest training row (LoadData.py:114-128; CFFM never calls it)."""
+        n = min(len(r) for r in self.Train_data['X'])
+        for d in (self.Train_data, self.Validation_data, self.Test_data):
+            d['X'] = [r[:n] for r in d['X']]
+        return n
+
+    # -- extension: dense arrays for the device pipeline -------------------------------------------
+    @staticmethod
+    def packed(data):
+        """``{'X','Y'}`` -> (int32 [N,F], float32 [N]); requires equal-length rows."""
+        X = np.asarray(data['X'], dtype=np.int32)
+        if X.ndim != 2:
+            raise ValueError('rows have different lengths; the CFFM graph needs num_field ids per row')
+        return np.ascontiguousarray(X), np.asarray(data['Y'], dtype=np.float32)
