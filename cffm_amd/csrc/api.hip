@@ -1,0 +1,168 @@
+// Layout queries and the composite entry points (what CFFM.evaluate / CFFM.train call in place of the
+// two sess.run()s, CFFM.py:200 and :596).
+#include "common.hpp"
+
+#include <string.h>
+
+extern "C" int cffm_abi_version(void) { return CFFM_ABI_VERSION; }
+
+extern "C" const char* cffm_error_string(int err) {
+    switch (err) {
+        case 0: return "ok";
+        case CFFM_ERR_BAD_SHAPE: return "cffm: bad shape / argument";
+        case CFFM_ERR_UNSUPPORTED: return "cffm: unsupported configuration";
+        default: return hipGetErrorString((hipError_t)err);
+    }
+}
+
+extern "C" int cffm_theta_layout(const cffm_shape_t* s, cffm_theta_layout_t* out) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    memset(out, 0, sizeof(*out));
+    const Geo g = make_geo(s);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) / 4 * 4; return r; };   // 16-byte aligned members
+    out->att_W = take((int64_t)g.F * g.F);
+    out->att_b = take(g.F);
+    out->bias = take(1);
+    out->inner_cw = take(4);
+    out->inner_cb = take(2);
+    out->inner_dw = take((int64_t)g.P * g.K);
+    out->inner_db = take(1);
+    for (int l = 0; l < g.live; ++l) {
+        out->conv_w[l] = take((int64_t)4 * g.P * g.P);
+        out->conv_b[l] = take(g.P);
+    }
+    out->d1_w = take((int64_t)(2 * g.D - 2) * CFFM_HEAD_UNITS);
+    out->d1_b = take(CFFM_HEAD_UNITS);
+    out->d2_w = take(CFFM_HEAD_UNITS);
+    out->d2_b = take(1);
+    out->lin_w = take(g.F);
+    out->lin_b = take(1);
+    out->n = o;
+    out->P = g.P; out->Pp = g.Pp; out->Lc = g.Lc; out->live = g.live;
+    return 0;
+}
+
+extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t* out) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B < 1) return CFFM_ERR_BAD_SHAPE;
+    memset(out, 0, sizeof(*out));
+    const Geo g = make_geo(s);
+    cffm_theta_layout_t tl;
+    cffm_theta_layout(s, &tl);
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    const int64_t b = B;
+    out->gpart = take((int64_t)CFFM_NSLAB * tl.n * 4);           // first: its offset must not depend on B
+    out->scalars = take(16 * 4);
+    out->Ei = take(b * g.F * g.K * 4);
+    out->Eo = take(b * g.F * g.D * 4);
+    out->fb = take(b * g.F * 4);
+    out->inner_out = take(b * 4);
+    for (int l = 0; l < g.live; ++l) {
+        const int64_t S = g.D >> (l + 1);
+        out->C[l] = take(b * S * S * g.Pp * 4);
+    }
+    out->t1 = take(b * (2 * g.D - 2) * 4);
+    out->h1 = take(b * CFFM_HEAD_UNITS * 4);
+    out->att = take(b * g.F * 4);
+    out->out = take(b * 4);
+    out->sqerr = take(b * 4);
+    out->dout = take(b * 4);
+    out->dt1 = take(b * (2 * g.D - 2) * 4);
+    for (int l = 0; l < g.live; ++l) {
+        const int64_t S = g.D >> (l + 1);
+        out->dC[l] = take(b * S * S * g.Pp * 4);
+    }
+    out->dEi = take(b * g.F * g.K * 4);
+    out->dEo = take(b * g.F * g.D * 4);
+    out->dfb = take(b * g.F * 4);
+    const int64_t nrows = b * g.F;
+    out->sort_keys = take(nrows * 4);
+    out->sort_vals = take(nrows * 4);
+    out->sort_tmp_bytes = (nrows * 4 + 255) / 256 * 256 + nrows * 16 + (4 << 20);
+    out->sort_tmp = take(out->sort_tmp_bytes);
+    out->bytes = o;
+    return 0;
+}
+
+extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                            const float* y, int32_t B, void* ws, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    const Geo g = make_geo(s);
+    rc = cffm_gather(s, tab, ids, B, s->inner_conv ? (float*)(w + wl.Ei) : nullptr,
+                     s->outer_conv ? (float*)(w + wl.Eo) : nullptr, (float*)(w + wl.fb), stream);
+    if (rc) return rc;
+    if ((rc = cffm_inner_fwd(s, theta, ws, B, stream))) return rc;
+    if (s->outer_conv) {
+        if ((rc = cffm_outer_conv0_fwd(s, theta, ws, B, stream))) return rc;
+        for (int l = 1; l < g.live; ++l)
+            if ((rc = cffm_conv_fwd(s, theta, ws, B, l, stream))) return rc;
+    }
+    return cffm_head_fwd(s, theta, ws, y, B, stream);
+}
+
+extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                            int32_t B, void* ws, float* out, void* stream) {
+    int rc = cffm_forward(s, tab, theta, ids, nullptr, B, ws, stream);
+    if (rc || B <= 0) return rc;
+    if (out) {
+        cffm_ws_layout_t wl;
+        cffm_ws_layout(s, B, &wl);
+        hipError_t e = hipMemcpyAsync(out, (char*)ws + wl.out, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const float* y, int32_t B, int64_t B_global,
+                             void* ws, float* grad, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
+    cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
+    const Geo g = make_geo(s);
+    char* w = (char*)ws;
+    if (!s->inner_conv || !s->outer_conv || !s->linear_att) {   // slabs of a disabled branch must read as zeros
+        hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)CFFM_NSLAB * tl.n * 4, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    if ((rc = cffm_head_bwd(s, theta, ws, y, B, B_global, stream))) return rc;
+    if (s->outer_conv) {
+        for (int l = g.live - 1; l >= 1; --l)
+            if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
+        if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
+    }
+    if ((rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
+    return cffm_reduce_slabs(s, ws, grad, stream);
+}
+
+extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,
+                               float* theta, float* theta_acc, float* grad, const int32_t* ids, const float* y,
+                               int32_t B, void* ws, float* loss, void* stream) {
+    int rc = cffm_forward(s, tab, theta, ids, y, B, ws, stream);    // leaves scalars[3] = local loss-term sum
+    if (rc || B <= 0) return rc;
+    if ((rc = cffm_backward(s, theta, y, B, (int64_t)B, ws, grad, stream))) return rc;
+    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
+    cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
+    char* w = (char*)ws;
+    if ((rc = cffm_dense_adagrad(theta, theta_acc, grad, tl.n, s->lr, stream))) return rc;
+    rc = cffm_sparse_adagrad(s, tab, tab_acc, ids, (int64_t)B * s->F,
+                             s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
+                             s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb), ws, B,
+                             stream);
+    if (rc) return rc;
+    if (loss) {
+        hipError_t e = hipMemcpyAsync(loss, w + wl.scalars + 4, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}

@@ -1,0 +1,133 @@
+// Shared device helpers for the CFFM gfx950 kernels (wave64, fp32 MFMA, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cffm_hip.h"
+
+#define CFFM_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CFFM_CHECK_LAUNCH()                          \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+static inline int ceil_div_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int ilog2_i(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
+
+// Geometry derived from the shape; passed to kernels by value.
+struct Geo {
+    int M, F, K, D, P, Pp, Lc, live, act, linear_att;
+    float lamda_att, beta_outer;
+};
+
+static inline Geo make_geo(const cffm_shape_t* s) {
+    Geo g;
+    g.M = s->M; g.F = s->F; g.K = s->K; g.D = s->D;
+    g.P = s->F * (s->F - 1) / 2;
+    g.Pp = (g.P + 15) / 16 * 16;
+    g.Lc = ilog2_i(s->D);
+    g.live = g.Lc - 1;
+    g.act = s->act; g.linear_att = s->linear_att;
+    g.lamda_att = s->lamda_att; g.beta_outer = s->beta_outer;
+    return g;
+}
+
+static inline int check_shape(const cffm_shape_t* s) {
+    if (!s) return CFFM_ERR_BAD_SHAPE;
+    if (s->F < 2 || s->F > CFFM_MAX_FIELDS) return CFFM_ERR_BAD_SHAPE;
+    if (s->D < 4 || (s->D & (s->D - 1))) return CFFM_ERR_BAD_SHAPE;
+    if (s->K < 4 || (s->K & 3)) return CFFM_ERR_BAD_SHAPE;          // float4 rows
+    if (s->M < 1) return CFFM_ERR_BAD_SHAPE;
+    if (ilog2_i(s->D) - 1 > CFFM_MAX_LAYERS) return CFFM_ERR_BAD_SHAPE;
+    if (s->act < 0 || s->act > CFFM_ACT_GELU) return CFFM_ERR_BAD_SHAPE;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations, TF-1.14 functor semantics
+// ---------------------------------------------------------------------------------------------
+#define CFFM_SELU_SCALE 1.0507009873554804934193349852946f
+#define CFFM_SELU_SCALE_ALPHA 1.7580993408473768599402175208123f
+
+__device__ __forceinline__ float act_f(float x, int act) {
+    switch (act) {
+        case CFFM_ACT_RELU: return fmaxf(x, 0.f);
+        case CFFM_ACT_PRELU: return fmaxf(x, 0.f) + 0.25f * (-fmaxf(-x, 0.f));
+        case CFFM_ACT_ELU: return x < 0.f ? expf(x) - 1.f : x;
+        case CFFM_ACT_SELU: return x < 0.f ? CFFM_SELU_SCALE_ALPHA * (expf(x) - 1.f) : CFFM_SELU_SCALE * x;
+        default: return x * (0.5f * (1.f + erff(x * 0.70710678118654752440f)));
+    }
+}
+
+// d act(x) / dx as TF autodiff yields it
+__device__ __forceinline__ float act_grad_f(float x, int act) {
+    switch (act) {
+        case CFFM_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case CFFM_ACT_PRELU: return x > 0.f ? 1.f : (x < 0.f ? 0.25f : 0.f);
+        case CFFM_ACT_ELU: return x < 0.f ? expf(x) : 1.f;                       // y + 1 for y < 0
+        case CFFM_ACT_SELU: return x < 0.f ? CFFM_SELU_SCALE_ALPHA * expf(x) : CFFM_SELU_SCALE;  // y + scale_alpha
+        default: {
+            float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+            float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+            return cdf + x * pdf;
+        }
+    }
+}
+
+// act on a value known to be >= 0 (output of the relu inside conv_layer, CFFM.py:478)
+__device__ __forceinline__ float act_pos(float c, int act) {
+    switch (act) {
+        case CFFM_ACT_SELU: return CFFM_SELU_SCALE * c;
+        case CFFM_ACT_GELU: return c * (0.5f * (1.f + erff(c * 0.70710678118654752440f)));
+        default: return c;   // relu / prelu / elu are the identity on [0, inf)
+    }
+}
+
+// d act(relu(z)) / dz expressed through c = relu(z)
+__device__ __forceinline__ float act_relu_grad(float c, int act) {
+    return c > 0.f ? act_grad_f(c, act) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Block-wide sum in a fixed order (bitwise reproducible); red must hold >= blockDim/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// pair p -> packed (i | j << 16) in the reference's row-major i<j order (CFFM.py:304-305)
+__device__ __forceinline__ void build_pair_lut(uint32_t* lut, int F, int Pp) {
+    for (int i = threadIdx.x; i < F; i += blockDim.x) {
+        int base = i * (2 * F - i - 1) / 2;
+        for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
+    }
+    const int P = F * (F - 1) / 2;
+    for (int p = P + threadIdx.x; p < Pp; p += blockDim.x) lut[p] = 0u;   // padded pairs -> (0,0), weights are 0
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

@@ -1,0 +1,704 @@
+// Outer-product / conv-stack contractions of the CFFM graph on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+//   conv_fwd<GEN=true>   CFFM.py:355-367 + :385-386 (i = 0): the F x F outer-product map is never
+//                        materialised; the A operand of the implicit GEMM is generated per lane from
+//                        the example's embedding tile held in LDS (two ds_read + one v_mul per element).
+//   conv_fwd<GEN=false>  CFFM.py:385-387 (i >= 1): 2x2 / stride-2 VALID conv as an implicit GEMM
+//                        M = B*So*So, N = P, K = 4P; the A operand is act(C_{l-1}) read straight from
+//                        HBM/L2 as 16-byte pieces of the four patch rows (no im2col buffer).
+//   dgrad<L0=false>      gradient wrt the layer input; patches never overlap, so it is a scatter-store
+//                        fused with the broadcast sum-pool gradient and the relu/act mask.
+//   dgrad<L0=true>       layer 0: the dA tile is contracted with the embedding tile straight into dEo
+//                        (per-wavefront private LDS accumulators, merged in wave order).
+//   wgrad<GEN>           weight/bias gradients: split-K over CFFM_NSLAB slabs, both operands via LDS.
+//
+// Tiling: 256-thread workgroups = 4 wavefronts; a wavefront owns RM x NT tiles of 16x16 (rows = output
+// positions, cols = output channels).  The weight tile of a 32-deep K step is shared by the four
+// wavefronts through a double-buffered LDS tile, one barrier per K step.  Inside a K step a lane holds
+// FOUR consecutive k of its row (one global_load_dwordx4) and feeds them to four MFMAs; the B fragment
+// uses the same k permutation, which the contraction does not care about.
+// Channels are padded to Pp = ceil16(P) in every activation tensor so that 16-byte pieces never
+// straddle a row and tiles never straddle a filter tap; padded channels hold zeros.
+#include "common.hpp"
+
+#define KSTEP 32
+
+struct RowPos { int b, y, x; };
+__device__ __forceinline__ RowPos row_pos(int64_t m, int lgSo) {
+    RowPos p;
+    const int So = 1 << lgSo;
+    p.x = (int)(m & (So - 1));
+    p.y = (int)((m >> lgSo) & (So - 1));
+    p.b = (int)(m >> (2 * lgSo));
+    return p;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Generic K loop: acc[RM][NT] += A(rows of this wave, K) * Wtile(K, BN).
+//   loadA(ks, areg): fills areg[RM][2] (float4 = 4 consecutive k of the lane's row, halves h = 0,1)
+//   loadW(ks, wreg): fills wreg[2*NT]; element e = tid + 256*i is tile[e / BN][e % BN], or with TRANS
+//                    tile[e % 32][e / 32] (lets the loader read a transposed weight contiguously)
+//   khalves: number of valid 16-deep halves (K / 16)
+// -------------------------------------------------------------------------------------------------
+template <int NT, int RM, bool TRANS, class LoadA, class LoadW>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, float* Ws, int nvalid,
+                                          LoadA loadA, LoadW loadW) {
+    constexpr int BN = NT * 16, LDW = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
+    const int nks = (khalves + 1) >> 1;
+    float4 areg[RM][2], anext[RM][2];
+    float wreg[2 * NT];
+    loadA(0, areg);
+    loadW(0, wreg);
+    __syncthreads();                          // previous users of Ws are done
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) {
+        const int e = tid + 256 * i;
+        Ws[TRANS ? (e % KSTEP) * LDW + (e / KSTEP) : (e / BN) * LDW + (e % BN)] = wreg[i];
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;
+        if (more) {
+            loadA(ks + 1, anext);
+            loadW(ks + 1, wreg);
+        }
+        const float* Wb = Ws + (ks & 1) * (KSTEP * LDW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (2 * ks + h < khalves) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int krow = 16 * h + 4 * kk + t;
+                    float bf[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bf[nt] = Wb[krow * LDW + nt * 16 + r];
+#pragma unroll
+                    for (int rm = 0; rm < RM; ++rm) {
+                        const float av = t == 0 ? areg[rm][h].x : t == 1 ? areg[rm][h].y : t == 2 ? areg[rm][h].z : areg[rm][h].w;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            if (nt < nvalid) acc[rm][nt] = mfma16(av, bf[nt], acc[rm][nt]);
+                    }
+                }
+            }
+        }
+        if (more) {
+            float* Wn = Ws + ((ks + 1) & 1) * (KSTEP * LDW);
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {
+                const int e = tid + 256 * i;
+                Wn[TRANS ? (e % KSTEP) * LDW + (e / KSTEP) : (e / BN) * LDW + (e % BN)] = wreg[i];
+            }
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) { areg[rm][0] = anext[rm][0]; areg[rm][1] = anext[rm][1]; }
+        }
+        __syncthreads();
+    }
+}
+
+// stage the embedding rows of examples [b0, b0 + n_ex) into LDS with row pitch Dp = D + 1
+__device__ __forceinline__ void stage_examples(float* Es, const float* __restrict__ Eo, int b0, int n_ex, int B,
+                                               int F, int D, int Dp) {
+    const int per = F * D;
+    for (int e = threadIdx.x; e < n_ex * per; e += blockDim.x) {
+        const int ex = e / per, rem = e - ex * per, f = rem / D, d = rem - f * D;
+        const int b = b0 + ex;
+        Es[(ex * F + f) * Dp + d] = b < B ? Eo[(int64_t)b * per + rem] : 0.f;
+    }
+}
+
+struct ConvArgs {
+    const float* in;     // GEN: Eo [B,F,D]; else C_{l-1} [B,Sin,Sin,Pp]
+    const float* W;      // HWIO [2,2,P,P] = [4P][P]
+    const float* bias;   // [P]
+    float* out;          // relu(conv + bias) [B,So,So,Pp]
+    int64_t Mtot;        // B*So*So
+    int B, lgSo, P, Pp, F, D, act;
+};
+
+template <int NT, int RM, bool GEN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ws = reinterpret_cast<float*>(smem);                    // [2][32][LDW]
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + 2 * KSTEP * LDW);   // [Pp]   (GEN)
+    float* Es = reinterpret_cast<float*>(lut + a.Pp);             // [n_ex][F][Dp] (GEN)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int nvalid = min(NT, (Pp - n0) / 16);
+
+    int64_t abase[RM];   // !GEN: float offset of the (dh=0,dw=0) patch row piece of this lane
+    int iy[RM], jx[RM];  // GEN: LDS offsets of Eo[ex][0][2y] and Eo[ex][0][2x]
+    const int b0 = (int)(m0 >> (2 * a.lgSo));
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+        int64_t m = m0 + wave * (16 * RM) + rm * 16 + r;
+        if (m >= a.Mtot) m = a.Mtot - 1;
+        const RowPos rp = row_pos(m, a.lgSo);
+        if (GEN) {
+            const int eoff = (rp.b - b0) * a.F * Dp;
+            iy[rm] = eoff + 2 * rp.y;
+            jx[rm] = eoff + 2 * rp.x;
+        } else {
+            abase[rm] = (((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp + 4 * kk;
+        }
+    }
+    if (GEN) {
+        const int S2 = So * So;
+        const int n_ex = BM > S2 ? BM / S2 : 1;
+        build_pair_lut(lut, a.F, Pp);
+        stage_examples(Es, a.in, b0, n_ex, a.B, a.F, a.D, Dp);
+        __syncthreads();
+    }
+
+    auto loadA = [&](int ks, float4 (&reg)[RM][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = ks * KSTEP + 16 * h;
+            const int tap = k / Pp, pb = k - tap * Pp, dh = tap >> 1, dw = tap & 1;
+            if (GEN) {
+                const uint4 l4 = *reinterpret_cast<const uint4*>(&lut[pb + 4 * kk]);
+                const uint32_t ij[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    float v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = ij[t] & 0xffff, j = ij[t] >> 16;
+                        v[t] = Es[iy[rm] + i * Dp + dh] * Es[jx[rm] + j * Dp + dw];
+                    }
+                    reg[rm][h] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                const int64_t toff = (int64_t)(dh * Sin + dw) * Pp + pb;
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    float4 c = *reinterpret_cast<const float4*>(a.in + abase[rm] + toff);
+                    c.x = act_pos(c.x, a.act); c.y = act_pos(c.y, a.act);
+                    c.z = act_pos(c.z, a.act); c.w = act_pos(c.w, a.act);
+                    reg[rm][h] = c;
+                }
+            }
+        }
+    };
+    auto loadW = [&](int ks, float (&wreg)[2 * NT]) {
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int e = tid + 256 * i, kr = e / BN, c = e % BN;
+            const int k = ks * KSTEP + kr, tap = k / Pp, p = k - tap * Pp, n = n0 + c;
+            wreg[i] = (p < P && n < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + n] : 0.f;
+        }
+    };
+
+    f32x4 acc[RM][NT];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, nvalid, loadA, loadW);
+
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nvalid) continue;
+            const int n = n0 + nt * 16 + r;
+            const float bv = n < P ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                if (m < a.Mtot) a.out[m * Pp + n] = fmaxf(acc[rm][nt][j] + bv, 0.f);   // CFFM.py:478
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dgrad
+// -------------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float* dC;     // grad wrt C_l [B,So,So,Pp]
+    const float* W;      // [4P][P]
+    const float* Cprev;  // L0=false: C_{l-1} [B,Sin,Sin,Pp];  L0=true: Eo [B,F,D]
+    const float* dt1;    // [B, t1w]
+    float* dprev;        // L0=false: dC_{l-1};  L0=true: dEo [B,F,D]
+    int64_t Mtot;
+    int B, lgSo, P, Pp, F, D, act, t1w, t1off;   // t1off: offset of this layer's input pool inside t1
+};
+
+template <int NT, int RM, bool L0>
+__global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
+    constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ws = reinterpret_cast<float*>(smem);
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + 2 * KSTEP * LDW);   // L0 only from here on
+    float* Es = reinterpret_cast<float*>(lut + a.Pp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
+    const int Ntot = 4 * Pp;
+    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
+    const int n_ex = L0 ? rows_per_wg / S2 : 0;
+    const int mtiles = rows_per_wg / BM;
+    const int nblocks = L0 ? (Ntot + BN - 1) / BN : 1;
+    const int64_t wg_m0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
+    const int exsz = a.F * Dp;
+    float* dEw = Es + n_ex * exsz + wave * (n_ex * exsz);     // this wave's private accumulators
+    float* rs = Es + 5 * n_ex * exsz;                          // [n_ex][F] row sums, then [n_ex][F] dots
+    if (L0) {
+        build_pair_lut(lut, a.F, Pp);
+        stage_examples(Es, a.Cprev, b0, n_ex, a.B, a.F, a.D, Dp);
+        for (int e = tid; e < 4 * n_ex * exsz; e += 256) Es[n_ex * exsz + e] = 0.f;
+        __syncthreads();
+    }
+
+    for (int mt = 0; mt < mtiles; ++mt) {
+        const int64_t m0 = wg_m0 + (int64_t)mt * BM;
+        int64_t arow[RM];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+            int64_t m = m0 + wave * (16 * RM) + rm * 16 + r;
+            if (m >= a.Mtot) m = a.Mtot - 1;
+            arow[rm] = m * Pp + 4 * kk;
+        }
+        for (int nb = 0; nb < nblocks; ++nb) {
+            const int n0 = (L0 ? nb : blockIdx.y) * BN;
+            const int nvalid = min(NT, (Ntot - n0) / 16);
+            auto loadA = [&](int ks, float4 (&reg)[RM][2]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = ks * KSTEP + 16 * h;
+#pragma unroll
+                    for (int rm = 0; rm < RM; ++rm)
+                        reg[rm][h] = k < Pp ? *reinterpret_cast<const float4*>(a.dC + arow[rm] + k)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            auto loadW = [&](int ks, float (&wreg)[2 * NT]) {   // W^T tile: [q][n], global read contiguous in q
+#pragma unroll
+                for (int i = 0; i < 2 * NT; ++i) {
+                    const int e = tid + 256 * i, c = e / KSTEP, kr = e % KSTEP;
+                    const int q = ks * KSTEP + kr, n = n0 + c, tap = n / Pp, p = n - tap * Pp;
+                    wreg[i] = (q < P && p < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + q] : 0.f;
+                }
+            };
+            f32x4 acc[RM][NT];
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, nvalid, loadA, loadW);
+
+            // ---- epilogue ------------------------------------------------------------------------
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt >= nvalid) continue;
+                    const int n = n0 + nt * 16 + r, tap = n / Pp, p = n - tap * Pp, dh = tap >> 1, dw = tap & 1;
+                    if (!L0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                            if (m < a.Mtot) {
+                                const RowPos rp = row_pos(m, a.lgSo);
+                                const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * Pp + p;
+                                const float g = acc[rm][nt][j] + a.dt1[(int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y + dh];
+                                a.dprev[pos] = g * act_relu_grad(a.Cprev[pos], a.act);
+                            }
+                        }
+                    } else {
+                        const uint32_t ij = lut[p];
+                        const int fi = ij & 0xffff, fj = ij >> 16;
+                        const bool pv = p < P;
+                        if (a.lgSo >= 4) {
+                            // the 16 rows of this tile share (b, y): reduce the i-side over x in registers
+                            const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
+                            const RowPos rp = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);
+                            const int eb = (rp.b - b0) * exsz;
+                            const float ei = Es[eb + fi * Dp + 2 * rp.y + dh];
+                            float si = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool ok = pv && (mrow + j < a.Mtot);
+                                const float v = ok ? acc[rm][nt][j] : 0.f;
+                                const int xo = 2 * (rp.x + j) + dw;
+                                si += v * Es[eb + fj * Dp + xo];
+                                if (ok) atomicAdd(&dEw[eb + fj * Dp + xo], v * ei);
+                            }
+                            si += __shfl_xor(si, 16, 64);
+                            si += __shfl_xor(si, 32, 64);
+                            if (kk == 0 && pv) atomicAdd(&dEw[eb + fi * Dp + 2 * rp.y + dh], si);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                                if (pv && m < a.Mtot) {
+                                    const RowPos rp = row_pos(m, a.lgSo);
+                                    const int eb = (rp.b - b0) * exsz;
+                                    const int io = eb + fi * Dp + 2 * rp.y + dh, jo = eb + fj * Dp + 2 * rp.x + dw;
+                                    const float v = acc[rm][nt][j];
+                                    atomicAdd(&dEw[io], v * Es[jo]);
+                                    atomicAdd(&dEw[jo], v * Es[io]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (L0) {
+        // merge the four private copies in wave order and add the closed-form sum-pool (s0) terms:
+        //   dEo[i][h] += ds0[h] * R_i + Q_i,  R_i = sum_{j>i} rowsum(Eo[j]),  Q_i = sum_{i'<i} <ds0, Eo[i']>
+        __syncthreads();
+        float* acc0 = Es + n_ex * exsz;
+        float* dots = rs + n_ex * a.F;
+        for (int e = tid; e < n_ex * a.F; e += 256) {
+            const int ex = e / a.F, f = e - ex * a.F, b = b0 + ex;
+            float s = 0.f, d = 0.f;
+            if (b < a.B)
+                for (int h = 0; h < a.D; ++h) {
+                    const float v = Es[(ex * a.F + f) * Dp + h];
+                    s += v;
+                    d += v * a.dt1[(int64_t)b * a.t1w + h];
+                }
+            rs[e] = s; dots[e] = d;
+        }
+        __syncthreads();
+        const int per = a.F * a.D;
+        for (int e = tid; e < n_ex * per; e += 256) {
+            const int ex = e / per, rem = e - ex * per, f = rem / a.D, h = rem - f * a.D, b = b0 + ex;
+            if (b >= a.B) continue;
+            float R = 0.f, Q = 0.f;
+            for (int j = f + 1; j < a.F; ++j) R += rs[ex * a.F + j];
+            for (int i = 0; i < f; ++i) Q += dots[ex * a.F + i];
+            const int o = (ex * a.F + f) * Dp + h, st = n_ex * exsz;
+            const float conv = ((acc0[o] + acc0[st + o]) + acc0[2 * st + o]) + acc0[3 * st + o];
+            a.dprev[(int64_t)b * per + rem] = conv + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// wgrad: dW[(tap,p)][q] = sum_m A'[m][(tap,p)] * dC[m][q],  db[q] = sum_m dC[m][q]
+// grid = (i-blocks * q-blocks, CFFM_NSLAB); slab s reduces a contiguous chunk of the M rows.
+// -------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* in;     // GEN: Eo [B,F,D]; else C_{l-1} [B,Sin,Sin,Pp]
+    const float* dC;     // [Mtot][Pp]
+    float* slabW;        // slab 0 of conv_w[l]
+    float* slabB;        // slab 0 of conv_b[l]
+    int64_t slab_stride, Mtot;
+    int B, lgSo, P, Pp, F, D, act, qblocks;
+};
+
+template <int NT, bool GEN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int BI = 64, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Bs = reinterpret_cast<float*>(smem);                       // [KM][LDB]
+    float* As = Bs + KM * LDB;                                        // [KM][LDA]      (!GEN)
+    uint32_t* lut = reinterpret_cast<uint32_t*>(As + (GEN ? 0 : KM * LDA));   // [Pp]  (GEN)
+    float* Es = reinterpret_cast<float*>(lut + (GEN ? a.Pp : 0));     // [n_ex][F][Dp] (GEN)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
+    const int ib = blockIdx.x / a.qblocks, qb = blockIdx.x - ib * a.qblocks;
+    const int i0 = ib * BI, q0 = qb * BQ;
+    const int nvalid = min(NT, (Pp - q0) / 16);
+    const int slab = blockIdx.y;
+    const int64_t nsteps = (a.Mtot + KM - 1) / KM;
+    const int64_t cps = (nsteps + gridDim.y - 1) / gridDim.y;
+    const int64_t s_lo = slab * cps, s_hi = min(nsteps, s_lo + cps);
+    const int n_ex = GEN ? (KM > S2 ? KM / S2 : 1) : 0;
+
+    // the (tap, p) this lane's A' row belongs to
+    const int irow = i0 + wave * 16 + r;
+    const int tapA = irow / Pp, pA = irow - tapA * Pp, dhA = tapA >> 1, dwA = tapA & 1;
+    int fi = 0, fj = 0;
+    if (GEN) {
+        build_pair_lut(lut, a.F, Pp);
+        __syncthreads();
+        const uint32_t ij = lut[pA];
+        fi = ij & 0xffff; fj = ij >> 16;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    int cur_b = -1;
+
+    for (int64_t st = s_lo; st < s_hi; ++st) {
+        const int64_t mbase = st * KM;
+        // ---- global -> registers ----------------------------------------------------------------
+        float breg[2 * NT];
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int e = tid + 256 * i, row = e / BQ, c = e % BQ;
+            const int64_t m = mbase + row;
+            breg[i] = (m < a.Mtot && q0 + c < Pp) ? a.dC[m * Pp + q0 + c] : 0.f;
+        }
+        float4 areg[2];
+        if (!GEN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int u = tid + 256 * i, row = u / 16, c4 = u % 16;
+                const int64_t m = mbase + row;
+                const int ii = i0 + 4 * c4, tap = ii / Pp, p = ii - tap * Pp;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.Mtot) {
+                    const RowPos rp = row_pos(m, a.lgSo);
+                    const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + (tap >> 1)) * Sin + 2 * rp.x + (tap & 1)) * Pp + p;
+                    v = *reinterpret_cast<const float4*>(a.in + pos);
+                    v.x = act_pos(v.x, a.act); v.y = act_pos(v.y, a.act);
+                    v.z = act_pos(v.z, a.act); v.w = act_pos(v.w, a.act);
+                }
+                areg[i] = v;
+            }
+        }
+        __syncthreads();                                   // previous step's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int e = tid + 256 * i;
+            Bs[(e / BQ) * LDB + (e % BQ)] = breg[i];
+        }
+        if (!GEN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int u = tid + 256 * i;
+                *reinterpret_cast<float4*>(&As[(u / 16) * LDA + 4 * (u % 16)]) = areg[i];
+            }
+        } else {
+            const int bl = (int)(mbase >> (2 * a.lgSo));
+            if (bl != cur_b) {
+                stage_examples(Es, a.in, bl, n_ex, a.B, a.F, a.D, Dp);
+                cur_b = bl;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over the 32 rows ------------------------------------------------------------------
+#pragma unroll
+        for (int ks4 = 0; ks4 < KM; ks4 += 4) {
+            float av;
+            if (GEN) {
+                int64_t m = mbase + ks4 + kk;
+                if (m >= a.Mtot) m = a.Mtot - 1;             // B' rows beyond Mtot are zero
+                const RowPos rp = row_pos(m, a.lgSo);
+                const int eb = (rp.b - cur_b) * a.F * Dp;
+                av = Es[eb + fi * Dp + 2 * rp.y + dhA] * Es[eb + fj * Dp + 2 * rp.x + dwA];
+            } else {
+                av = As[(ks4 + kk) * LDA + wave * 16 + r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nt < nvalid) acc[nt] = mfma16(av, Bs[(ks4 + kk) * LDB + nt * 16 + r], acc[nt]);
+        }
+        if (ib == 0 && tid < BQ) {
+#pragma unroll 8
+            for (int row = 0; row < KM; ++row) bsum += Bs[row * LDB + tid];
+        }
+    }
+    // ---- write this slab (every element of the parameter range, zeros included) ---------------------
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt >= nvalid) continue;
+        const int q = q0 + nt * 16 + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + wave * 16 + kk * 4 + j, tap = i / Pp, p = i - tap * Pp;
+            if (p < P && q < P && tap < 4) sw[(int64_t)(tap * P + p) * P + q] = acc[nt][j];
+        }
+    }
+    if (ib == 0 && tid < BQ && q0 + tid < P) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static inline void pick_nt(int tiles, int* nblk, int* NT) {
+    int nb = (tiles + 7) / 8;
+    int need = (tiles + nb - 1) / nb;
+    static const int allowed[6] = {1, 2, 3, 4, 6, 8};
+    int nt = 8;
+    for (int i = 0; i < 6; ++i)
+        if (allowed[i] >= need) { nt = allowed[i]; break; }
+    *NT = nt;
+    *nblk = (tiles + nt - 1) / nt;
+}
+
+#define DISPATCH_NT(NTV, CALL)                     \
+    switch (NTV) {                                 \
+        case 1: { constexpr int NT_ = 1; CALL; } break; \
+        case 2: { constexpr int NT_ = 2; CALL; } break; \
+        case 3: { constexpr int NT_ = 3; CALL; } break; \
+        case 4: { constexpr int NT_ = 4; CALL; } break; \
+        case 6: { constexpr int NT_ = 6; CALL; } break; \
+        default: { constexpr int NT_ = 8; CALL; } break; \
+    }
+
+template <class KernelT>
+static inline int set_lds(KernelT k, size_t lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <int NT, int RM, bool GEN>
+static int launch_conv_fwd(const ConvArgs& a, int nblk, hipStream_t st) {
+    constexpr int BM = 64 * RM;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int n_ex = GEN ? (BM > S2 ? BM / S2 : 1) : 0;
+    const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 0) + 4) * 4;
+    int rc = set_lds(conv_fwd_kernel<NT, RM, GEN>, lds);
+    if (rc) return rc;
+    dim3 grid((unsigned)((a.Mtot + BM - 1) / BM), nblk);
+    hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN>), grid, dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT, int RM, bool L0>
+static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
+    constexpr int BM = 64 * RM;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
+    const int n_ex = L0 ? rows_per_wg / S2 : 0;
+    const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (L0 ? a.Pp + 5 * n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F : 0) + 4) * 4;
+    int rc = set_lds(dgrad_kernel<NT, RM, L0>, lds);
+    if (rc) return rc;
+    dim3 grid((unsigned)((a.Mtot + rows_per_wg - 1) / rows_per_wg), L0 ? 1 : nblk);
+    hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0>), grid, dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT, bool GEN>
+static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    constexpr int BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
+    const int S2 = 1 << (2 * a.lgSo);
+    const int n_ex = GEN ? (32 > S2 ? 32 / S2 : 1) : 0;
+    const size_t lds = (size_t)(32 * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 32 * 80) + 4) * 4;
+    int rc = set_lds(wgrad_kernel<NT, GEN>, lds);
+    if (rc) return rc;
+    dim3 grid((unsigned)((4 * a.Pp / 64) * a.qblocks), CFFM_NSLAB);
+    hipLaunchKernelGGL((wgrad_kernel<NT, GEN>), grid, dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int64_t layer_rows(const Geo& g, int B, int l, int* lgSo) {
+    const int So = g.D >> (l + 1);
+    *lgSo = ilog2_i(So);
+    return (int64_t)B * So * So;
+}
+// offset inside t1 of the pool taken from the INPUT of layer l (s_l), width D >> l
+static inline int t1_offset(const Geo& g, int l) {
+    int off = 0;
+    for (int i = 0; i < l; ++i) off += g.D >> i;
+    return off;
+}
+
+static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    if (l < 0 || l >= g.live) return CFFM_ERR_BAD_SHAPE;
+    char* w = (char*)ws;
+    ConvArgs a;
+    a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
+    a.W = theta + tl.conv_w[l]; a.bias = theta + tl.conv_b[l];
+    a.out = (float*)(w + wl.C[l]);
+    a.Mtot = layer_rows(g, B, l, &a.lgSo);
+    a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+    int nblk, NT;
+    pick_nt(g.Pp / 16, &nblk, &NT);
+    const bool big = a.Mtot >= 128 * 256;
+    int rc = 0;
+    if (l == 0) {
+        if (big) { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 2, true>(a, nblk, st))); }
+        else { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 1, true>(a, nblk, st))); }
+    } else {
+        if (big) { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 2, false>(a, nblk, st))); }
+        else { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 1, false>(a, nblk, st))); }
+    }
+    return rc;
+}
+
+static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    if (l < 0 || l >= g.live) return CFFM_ERR_BAD_SHAPE;
+    char* w = (char*)ws;
+    float* gpart = (float*)(w + wl.gpart);
+    int rc = 0;
+    {   // weight / bias gradient
+        WgradArgs a;
+        a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
+        a.dC = (const float*)(w + wl.dC[l]);
+        a.slabW = gpart + tl.conv_w[l]; a.slabB = gpart + tl.conv_b[l];
+        a.slab_stride = tl.n;
+        a.Mtot = layer_rows(g, B, l, &a.lgSo);
+        a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+        int NT;
+        pick_nt(g.Pp / 16, &a.qblocks, &NT);
+        if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
+        else { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, false>(a, st))); }
+        if (rc) return rc;
+    }
+    {   // input gradient
+        DgradArgs a;
+        a.dC = (const float*)(w + wl.dC[l]);
+        a.W = theta + tl.conv_w[l];
+        a.Cprev = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
+        a.dt1 = (const float*)(w + wl.dt1);
+        a.dprev = (float*)(w + (l == 0 ? wl.dEo : wl.dC[l - 1]));
+        a.Mtot = layer_rows(g, B, l, &a.lgSo);
+        a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+        a.t1w = 2 * g.D - 2; a.t1off = t1_offset(g, l);
+        int nblk, NT;
+        pick_nt(4 * g.Pp / 16, &nblk, &NT);
+        const bool big = a.Mtot >= 128 * 256;
+        if (l == 0) {
+            if (big) { DISPATCH_NT(NT, rc = (launch_dgrad<NT_, 2, true>(a, nblk, st))); }
+            else { DISPATCH_NT(NT, rc = (launch_dgrad<NT_, 1, true>(a, nblk, st))); }
+        } else {
+            if (big) { DISPATCH_NT(NT, rc = (launch_dgrad<NT_, 2, false>(a, nblk, st))); }
+            else { DISPATCH_NT(NT, rc = (launch_dgrad<NT_, 1, false>(a, nblk, st))); }
+        }
+    }
+    return rc;
+}
+
+extern "C" int cffm_outer_conv0_fwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0 || !s->outer_conv) return 0;
+    return conv_fwd_any(s, theta, ws, B, 0, (hipStream_t)stream);
+}
+extern "C" int cffm_conv_fwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0 || !s->outer_conv) return 0;
+    if (layer < 1) return CFFM_ERR_BAD_SHAPE;
+    return conv_fwd_any(s, theta, ws, B, layer, (hipStream_t)stream);
+}
+extern "C" int cffm_outer_conv0_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0 || !s->outer_conv) return 0;
+    return conv_bwd_any(s, theta, ws, B, 0, (hipStream_t)stream);
+}
+extern "C" int cffm_conv_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0 || !s->outer_conv) return 0;
+    if (layer < 1) return CFFM_ERR_BAD_SHAPE;
+    return conv_bwd_any(s, theta, ws, B, layer, (hipStream_t)stream);
+}

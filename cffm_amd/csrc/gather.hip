@@ -1,0 +1,76 @@
+// Embedding row gather: tf.nn.embedding_lookup x3 (CFFM.py:303, :354, :422).
+//
+// HBM-bound.  A row is K*4 (inner) or D*4 (outer) contiguous bytes; one lane moves 16 B
+// (global_load_dwordx4), so a row of 32 floats is 8 consecutive lanes and a wavefront moves
+// 8 whole rows per instruction (4 rows at 64 floats).  The id of a slot is read by all lanes of that
+// slot (same address -> one broadcast fetch).  The 4-byte feature_bias rows are gathered by a
+// separate slot-per-lane grid tail so that they do not put a divergent scalar load in the row path.
+#include "common.hpp"
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const float* __restrict__ inner, const float* __restrict__ outer, const float* __restrict__ fbias,
+    const int32_t* __restrict__ ids, int64_t n_slots, int K4, int D4,
+    float* __restrict__ Ei, float* __restrict__ Eo, float* __restrict__ fb, int M) {
+    const int CH = K4 + D4;                       // 16-byte chunks per slot across both tables
+    const int64_t total = n_slots * CH;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // UNROLL independent row pieces in flight per lane before the first store
+    for (; g0 < total; g0 += stride * UNROLL) {
+        float4 v[UNROLL];
+        int64_t dst[UNROLL];
+        int which[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t g = g0 + u * stride;
+            which[u] = -1;
+            if (g < total) {
+                const int64_t slot = g / CH;
+                const int ch = (int)(g - slot * CH);
+                int id = ids[slot];
+                id = id < 0 ? 0 : (id >= M ? M - 1 : id);   // clamp: a bad id must not fault the GPU
+                if (ch < K4) {
+                    which[u] = 0;
+                    dst[u] = slot * K4 + ch;
+                    v[u] = reinterpret_cast<const float4*>(inner)[(int64_t)id * K4 + ch];
+                } else {
+                    which[u] = 1;
+                    dst[u] = slot * D4 + (ch - K4);
+                    v[u] = reinterpret_cast<const float4*>(outer)[(int64_t)id * D4 + (ch - K4)];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (which[u] == 0) reinterpret_cast<float4*>(Ei)[dst[u]] = v[u];
+            else if (which[u] == 1) reinterpret_cast<float4*>(Eo)[dst[u]] = v[u];
+        }
+    }
+    if (fb != nullptr) {
+        for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
+            int id = ids[s];
+            id = id < 0 ? 0 : (id >= M ? M - 1 : id);
+            fb[s] = fbias[id];
+        }
+    }
+}
+
+extern "C" int cffm_gather(const cffm_shape_t* s, const cffm_tables_t* t, const int32_t* ids, int32_t B,
+                           float* Ei, float* Eo, float* fb, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if ((s->D & 3) || (s->K & 3)) return CFFM_ERR_BAD_SHAPE;
+    const int64_t n_slots = (int64_t)B * s->F;
+    const int K4 = Ei ? s->K / 4 : 0, D4 = Eo ? s->D / 4 : 0;
+    const int64_t total = n_slots * (K4 + D4);
+    int64_t work = total > n_slots ? total : n_slots;
+    int blocks = (int)((work + 256 * 4 - 1) / (256 * 4));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       t->inner_emb, t->outer_emb, t->feat_bias, ids, n_slots, K4, D4, Ei, Eo, fb, s->M);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

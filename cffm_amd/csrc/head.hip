@@ -1,0 +1,320 @@
+// Head of the CFFM graph: sum pooling over the conv stack (CFFM.py:381, :390-396), the two dense
+// layers of the outer branch (:409-414), the linear-attention first-order term (:422-446), add_n (:453),
+// the loss terms (:486-514) and all of their gradients.
+//
+// Everything here is tiny per example except the pooling sweep, which re-reads the conv outputs once
+// (contiguous S*Pp-float rows, 16-byte loads) - HBM/L2-bound and bitwise reproducible (fixed tree).
+#include "common.hpp"
+
+struct HeadArgs {
+    Geo g;
+    int B;
+    const float* Eo;          // [B,F,D]
+    const float* fb;          // [B,F]
+    const float* inner_out;   // [B]
+    const float* C[CFFM_MAX_LAYERS];
+    const float *d1_w, *d1_b, *d2_w, *d2_b, *att_W, *att_b, *lin_w, *lin_b, *bias;
+    const float* y;           // may be NULL
+    float *t1, *h1, *att, *out, *sqerr;
+    int loss, inner_conv, outer_conv;
+};
+
+__device__ __forceinline__ float loss_term(float out_raw, float y, int loss, float* out_eval) {
+    switch (loss) {
+        case CFFM_LOSS_MAE: *out_eval = out_raw; return fabsf(y - out_raw);
+        case CFFM_LOSS_LOG: {
+            const float s = 1.f / (1.f + expf(-out_raw));
+            *out_eval = s;                                         // CFFM.py:496
+            return -(y * logf(s + 1e-7f) + (1.f - y) * logf(1.f - s + 1e-7f));
+        }
+        default: *out_eval = out_raw; return (y - out_raw) * (y - out_raw);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    __shared__ float t1s[1024];
+    __shared__ float h1s[CFFM_HEAD_UNITS];
+    __shared__ float rs[CFFM_MAX_FIELDS];
+    __shared__ float sc[4];
+    const Geo& g = a.g;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t1w = 2 * g.D - 2;
+    float o = 0.f;
+    if (a.outer_conv) {
+        const float* E = a.Eo + (int64_t)b * g.F * g.D;
+        for (int f = wave; f < g.F; f += 4) {                       // row sums of the embedding tile
+            float s = 0.f;
+            for (int d = lane; d < g.D; d += 64) s += E[f * g.D + d];
+            s = wave_sum(s);
+            if (lane == 0) rs[f] = s;
+        }
+        __syncthreads();
+        // s0[h] = sum_{w,p} Eo[i_p][h] * Eo[j_p][w] = sum_i Eo[i][h] * sum_{j>i} rowsum(j)   (:381)
+        for (int h = tid; h < g.D; h += 256) {
+            float s = 0.f, R = 0.f;
+            for (int i = g.F - 2; i >= 0; --i) {
+                R += rs[i + 1];
+                s += E[i * g.D + h] * R;
+            }
+            t1s[h] = s;
+        }
+        // pools of the live layers: s_{l+1}[y] = sum_{x,q} act(C_l[b,y,x,q])                      (:390-391)
+        int off = g.D, item = 0;
+        for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
+            const int S = g.D >> (l + 1);
+            const int n4 = S * g.Pp / 4;
+            for (int yy = 0; yy < S; ++yy, ++item) {
+                if ((item & 3) != wave) continue;
+                const float4* row = reinterpret_cast<const float4*>(a.C[l] + ((int64_t)b * S + yy) * S * g.Pp);
+                float s = 0.f;
+                for (int i = lane; i < n4; i += 64) {
+                    const float4 v = row[i];
+                    s += (act_pos(v.x, g.act) + act_pos(v.y, g.act)) + (act_pos(v.z, g.act) + act_pos(v.w, g.act));
+                }
+                s = wave_sum(s);
+                if (lane == 0) t1s[off + yy] = s;
+            }
+            off += S;
+        }
+        __syncthreads();
+        for (int k = tid; k < t1w; k += 256) a.t1[(int64_t)b * t1w + k] = t1s[k];
+        if (tid < CFFM_HEAD_UNITS) {                                 // dense(32), :409
+            float s = a.d1_b[tid];
+            for (int k = 0; k < t1w; ++k) s += t1s[k] * a.d1_w[k * CFFM_HEAD_UNITS + tid];
+            h1s[tid] = s;
+            a.h1[(int64_t)b * CFFM_HEAD_UNITS + tid] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {                                             // dense(1) * beta, :410, :414
+            float v = lane < CFFM_HEAD_UNITS ? h1s[lane] * a.d2_w[lane] : 0.f;
+            v = wave_sum(v);
+            if (lane == 0) sc[0] = g.beta_outer * (v + a.d2_b[0]);
+        }
+    }
+    if (wave == 1) {                                                 // first-order term, :422-446
+        const float fbv = lane < g.F ? a.fb[(int64_t)b * g.F + lane] : 0.f;
+        float lin;
+        if (g.linear_att) {
+            float z = lane < g.F ? a.att_b[lane] : 0.f;
+            for (int gI = 0; gI < g.F; ++gI) {
+                const float fg = __shfl(fbv, gI, 64);
+                if (lane < g.F) z += fg * a.att_W[gI * g.F + lane];
+            }
+            z = lane < g.F ? z / g.lamda_att : -INFINITY;
+            const float mx = wave_max(z);
+            const float e = lane < g.F ? expf(z - mx) : 0.f;
+            const float den = wave_sum(e);
+            const float at = e / den;
+            if (lane < g.F) a.att[(int64_t)b * g.F + lane] = at;
+            lin = wave_sum(lane < g.F ? fbv * at * a.lin_w[lane] : 0.f) + a.lin_b[0];
+        } else {
+            lin = wave_sum(fbv);
+        }
+        if (lane == 0) sc[1] = lin;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.outer_conv) o = sc[0];
+        float out = (a.inner_conv ? a.inner_out[b] : 0.f);
+        out += o;
+        out += sc[1];
+        out += a.bias[0];                                            // :449-453
+        float ev = out;
+        if (a.y) a.sqerr[b] = loss_term(out, a.y[b], a.loss, &ev);
+        else if (a.loss == CFFM_LOSS_LOG) ev = 1.f / (1.f + expf(-out));
+        a.out[b] = ev;
+    }
+}
+
+// deterministic single-workgroup sum of n floats -> dst[0] (and dst[3] when mirror != 0)
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float* dst, int mirror) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        dst[0] = s;
+        if (mirror) dst[3] = s;
+    }
+}
+
+struct HeadBwdArgs {
+    Geo g;
+    int B;
+    int64_t Bg;
+    const float *fb, *t1, *h1, *att, *out, *y, *Ctop;
+    const float *d1_w, *d2_w, *att_W, *lin_w;
+    float* scalars;
+    float *dout, *dt1, *dfb, *dCtop;
+    float *s_attW, *s_attb, *s_bias, *s_d1w, *s_d1b, *s_d2w, *s_d2b, *s_linw, *s_linb;   // slab 0 pointers
+    int64_t slab_stride;
+    int loss, outer_conv;
+};
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ float dh1s[CFFM_HEAD_UNITS];
+    __shared__ float dt1s[1024];
+    __shared__ float red[4];
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t1w = 2 * g.D - 2, FF = g.F * g.F;
+    const int64_t so = (int64_t)blockIdx.x * a.slab_stride;
+    float* s_attW = a.s_attW + so; float* s_d1w = a.s_d1w + so;
+    const float sum = a.scalars[3];
+    const float invB = 1.f / (float)a.Bg;
+    float L;
+    if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
+    else L = sum * invB;
+    if (blockIdx.x == 0 && tid == 0) a.scalars[1] = L;
+    float g_d2w = 0.f, g_d1b = 0.f, g_d2b = 0.f, g_bias = 0.f, g_linw = 0.f, g_linb = 0.f, g_attb = 0.f;
+    bool first = true;
+    const int off_top = [&] { int o = 0; for (int i = 0; i < g.live; ++i) o += g.D >> i; return o; }();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float out = a.out[b], y = a.y[b];
+        float d;
+        switch (a.loss) {
+            case CFFM_LOSS_SQUARE_RMSE: d = (out - y) * invB / L; break;
+            case CFFM_LOSS_MSE: d = 2.f * (out - y) * invB; break;
+            case CFFM_LOSS_MAE: d = (out > y ? 1.f : (out < y ? -1.f : 0.f)) * invB; break;
+            default: {
+                const float s = out;   // ws.out holds sigmoid(logit) for log_loss
+                d = -(y / (s + 1e-7f) - (1.f - y) / (1.f - s + 1e-7f)) * invB * s * (1.f - s);
+            }
+        }
+        if (tid == 0) { a.dout[b] = d; g_bias += d; }
+        __syncthreads();
+        if (a.outer_conv) {
+            const float dd = d * g.beta_outer;
+            if (tid < CFFM_HEAD_UNITS) {
+                const float v = dd * a.d2_w[tid];
+                dh1s[tid] = v;
+                g_d2w += a.h1[(int64_t)b * CFFM_HEAD_UNITS + tid] * dd;
+                g_d1b += v;
+            }
+            if (tid == 0) g_d2b += dd;
+            __syncthreads();
+            for (int k = tid; k < t1w; k += 256) {
+                float s = 0.f;
+                for (int q = 0; q < CFFM_HEAD_UNITS; ++q) s += dh1s[q] * a.d1_w[k * CFFM_HEAD_UNITS + q];
+                dt1s[k] = s;
+                a.dt1[(int64_t)b * t1w + k] = s;
+            }
+            for (int e = tid; e < t1w * CFFM_HEAD_UNITS; e += 256) {
+                const int k = e / CFFM_HEAD_UNITS, q = e % CFFM_HEAD_UNITS;
+                const float v = a.t1[(int64_t)b * t1w + k] * dh1s[q];
+                s_d1w[e] = first ? v : s_d1w[e] + v;
+            }
+            __syncthreads();
+            // gradient wrt the top live conv output: only its sum pool feeds the head
+            const int ntop = 4 * g.Pp;
+            for (int e = tid; e < ntop; e += 256) {
+                const int yy = e / (2 * g.Pp);
+                const int64_t idx = (int64_t)b * ntop + e;
+                a.dCtop[idx] = dt1s[off_top + yy] * act_relu_grad(a.Ctop[idx], g.act);
+            }
+        }
+        if (wave == 0) {
+            const float fbv = lane < g.F ? a.fb[(int64_t)b * g.F + lane] : 0.f;
+            if (g.linear_att) {
+                const float at = lane < g.F ? a.att[(int64_t)b * g.F + lane] : 0.f;
+                const float dg = lane < g.F ? d * a.lin_w[lane] : 0.f;
+                const float da = dg * fbv;
+                const float sda = wave_sum(da * at);
+                const float dz = at * (da - sda) / g.lamda_att;
+                float dfbv = dg * at;
+                for (int gI = 0; gI < g.F; ++gI) {
+                    const float dzg = __shfl(dz, gI, 64);
+                    if (lane < g.F) {
+                        dfbv += dzg * a.att_W[lane * g.F + gI];
+                        const float v = fbv * dzg;
+                        s_attW[lane * g.F + gI] = first ? v : s_attW[lane * g.F + gI] + v;
+                    }
+                }
+                if (lane < g.F) a.dfb[(int64_t)b * g.F + lane] = dfbv;
+                g_linw += fbv * at * d;
+                g_attb += dz;
+                if (lane == 0) g_linb += d;
+            } else if (lane < g.F) {
+                a.dfb[(int64_t)b * g.F + lane] = d;
+            }
+        }
+        first = false;
+    }
+    if (first) {
+        for (int e = tid; e < t1w * CFFM_HEAD_UNITS; e += 256) s_d1w[e] = 0.f;
+        for (int e = tid; e < FF; e += 256) s_attW[e] = 0.f;
+    }
+    if (tid < CFFM_HEAD_UNITS) {
+        a.s_d2w[so + tid] = g_d2w;
+        a.s_d1b[so + tid] = g_d1b;
+    }
+    if (tid < g.F) {
+        a.s_linw[so + tid] = g_linw;
+        a.s_attb[so + tid] = g_attb;
+    }
+    if (tid == 0) {
+        a.s_d2b[so] = g_d2b;
+        a.s_bias[so] = g_bias;
+        a.s_linb[so] = g_linb;
+    }
+    (void)red;
+}
+
+extern "C" int cffm_head_fwd(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (2 * s->D - 2 > 1024) return CFFM_ERR_UNSUPPORTED;
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    HeadArgs a;
+    a.g = make_geo(s); a.B = B;
+    a.Eo = (const float*)(w + wl.Eo); a.fb = (const float*)(w + wl.fb);
+    a.inner_out = (const float*)(w + wl.inner_out);
+    for (int l = 0; l < CFFM_MAX_LAYERS; ++l) a.C[l] = (const float*)(w + wl.C[l]);
+    a.d1_w = theta + tl.d1_w; a.d1_b = theta + tl.d1_b; a.d2_w = theta + tl.d2_w; a.d2_b = theta + tl.d2_b;
+    a.att_W = theta + tl.att_W; a.att_b = theta + tl.att_b; a.lin_w = theta + tl.lin_w; a.lin_b = theta + tl.lin_b;
+    a.bias = theta + tl.bias;
+    a.y = y;
+    a.t1 = (float*)(w + wl.t1); a.h1 = (float*)(w + wl.h1); a.att = (float*)(w + wl.att);
+    a.out = (float*)(w + wl.out); a.sqerr = (float*)(w + wl.sqerr);
+    a.loss = s->loss; a.inner_conv = s->inner_conv; a.outer_conv = s->outer_conv;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    CFFM_CHECK_LAUNCH();
+    if (y) {
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)(w + wl.sqerr),
+                           (int64_t)B, (float*)(w + wl.scalars), 1);
+        CFFM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int cffm_head_bwd(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B,
+                             int64_t B_global, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (2 * s->D - 2 > 1024) return CFFM_ERR_UNSUPPORTED;
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    float* gp = (float*)(w + wl.gpart);
+    HeadBwdArgs a;
+    a.g = make_geo(s); a.B = B; a.Bg = B_global;
+    a.fb = (const float*)(w + wl.fb); a.t1 = (const float*)(w + wl.t1); a.h1 = (const float*)(w + wl.h1);
+    a.att = (const float*)(w + wl.att); a.out = (const float*)(w + wl.out); a.y = y;
+    const int top = a.g.live - 1;
+    a.Ctop = (const float*)(w + wl.C[top]); a.dCtop = (float*)(w + wl.dC[top]);
+    a.d1_w = theta + tl.d1_w; a.d2_w = theta + tl.d2_w; a.att_W = theta + tl.att_W; a.lin_w = theta + tl.lin_w;
+    a.scalars = (float*)(w + wl.scalars);
+    a.dout = (float*)(w + wl.dout); a.dt1 = (float*)(w + wl.dt1); a.dfb = (float*)(w + wl.dfb);
+    a.s_attW = gp + tl.att_W; a.s_attb = gp + tl.att_b; a.s_bias = gp + tl.bias;
+    a.s_d1w = gp + tl.d1_w; a.s_d1b = gp + tl.d1_b; a.s_d2w = gp + tl.d2_w; a.s_d2b = gp + tl.d2_b;
+    a.s_linw = gp + tl.lin_w; a.s_linb = gp + tl.lin_b;
+    a.slab_stride = tl.n;
+    a.loss = s->loss; a.outer_conv = s->outer_conv;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(CFFM_NSLAB), dim3(256), 0, (hipStream_t)stream, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,124 @@
+// Optimiser step: tf.train.AdagradOptimizer(lr, initial_accumulator_value=1e-8).minimize (CFFM.py:523-524).
+//
+//   reduce_slabs    sum of the CFFM_NSLAB split-K partial gradients in slab order (bitwise reproducible)
+//   dense_adagrad   acc += g*g; v -= lr*g/sqrt(acc)                        (no epsilon, TF semantics)
+//   sparse_adagrad  IndexedSlices semantics: duplicate ids are summed FIRST, then one update per distinct
+//                   row; rows not in the batch and their accumulators are untouched.  Implemented as a
+//                   stable radix sort of (id, slot) followed by one wavefront per segment head that walks
+//                   its segment in slot order - HBM-bound: per distinct row 5 x (K+D+1) x 4 bytes.
+#include "common.hpp"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, int nslab,
+                                                           float* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];
+    grad[i] = s;
+}
+
+__global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ v, float* __restrict__ acc,
+                                                            const float* __restrict__ grad, int64_t n, float lr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i];
+    const float a = acc[i] + g * g;
+    acc[i] = a;
+    v[i] -= lr * g / sqrtf(a);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int32_t* v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+// one wavefront per sorted position; only segment heads do work
+__global__ __launch_bounds__(256) void sparse_adagrad_kernel(
+    const int32_t* __restrict__ keys, const int32_t* __restrict__ slots, int64_t n, int M, int K, int D,
+    const float* __restrict__ dEi, const float* __restrict__ dEo, const float* __restrict__ dfb,
+    float* __restrict__ inner, float* __restrict__ outer, float* __restrict__ fbias,
+    float* __restrict__ a_inner, float* __restrict__ a_outer, float* __restrict__ a_fbias, float lr) {
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pos >= n) return;
+    const int id = keys[pos];
+    if (pos > 0 && keys[pos - 1] == id) return;          // not a segment head
+    if (id < 0 || id >= M) return;
+    const int W = (dEi ? K : 0) + (dEo ? D : 0) + 1;     // columns: inner | outer | bias
+    const int Ki = dEi ? K : 0;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int c = c0 + lane;
+        float g = 0.f;
+        if (c < W) {
+            for (int64_t q = pos; q < n && keys[q] == id; ++q) {
+                const int64_t sl = slots[q];
+                g += c < Ki ? dEi[sl * K + c] : (c < W - 1 ? dEo[sl * D + (c - Ki)] : dfb[sl]);
+            }
+            float *vp, *ap;
+            if (c < Ki) { vp = inner + (int64_t)id * K + c; ap = a_inner + (int64_t)id * K + c; }
+            else if (c < W - 1) { vp = outer + (int64_t)id * D + (c - Ki); ap = a_outer + (int64_t)id * D + (c - Ki); }
+            else { vp = fbias + id; ap = a_fbias + id; }
+            const float a = *ap + g * g;
+            *ap = a;
+            *vp -= lr * g / sqrtf(a);
+        }
+    }
+}
+
+extern "C" int cffm_reduce_slabs(const cffm_shape_t* s, void* ws, float* grad, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, 1, &wl);   // gpart sits at a B-independent offset
+    const float* gpart = (const float*)((char*)ws + wl.gpart);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gpart, (int64_t)tl.n, (int)CFFM_NSLAB, grad);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cffm_dense_adagrad(float* theta, float* acc, const float* grad, int64_t n, float lr, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       theta, acc, grad, n, lr);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cffm_sparse_adagrad(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
+                                   const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo,
+                                   const float* dfb, void* ws, int32_t B_ws, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (n_rows <= 0) return 0;
+    if (n_rows > (int64_t)B_ws * s->F) return CFFM_ERR_BAD_SHAPE;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B_ws, &wl);
+    char* w = (char*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* keys_out = (int32_t*)(w + wl.sort_keys);
+    int32_t* vals_out = (int32_t*)(w + wl.sort_vals);
+    int32_t* iota = (int32_t*)(w + wl.sort_tmp);
+    const size_t iota_bytes = ((size_t)n_rows * 4 + 255) / 256 * 256;
+    void* tmp = (void*)(w + wl.sort_tmp + iota_bytes);
+    size_t tmp_bytes = 0;
+    int bits = 1;
+    while ((1ll << bits) < (long long)s->M && bits < 32) ++bits;
+    hipError_t e = rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, ids, keys_out, (const int32_t*)iota, vals_out,
+                                             (size_t)n_rows, 0u, (unsigned)bits, st);
+    if (e != hipSuccess) return (int)e;
+    if (iota_bytes + tmp_bytes > (size_t)wl.sort_tmp_bytes) return CFFM_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, iota, n_rows);
+    CFFM_CHECK_LAUNCH();
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, keys_out, (const int32_t*)iota, vals_out, (size_t)n_rows, 0u,
+                                  (unsigned)bits, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys_out, vals_out,
+                       n_rows, s->M, s->K, s->D, dEi, dEo, dfb, tab->inner_emb, tab->outer_emb, tab->feat_bias,
+                       acc->inner_emb, acc->outer_emb, acc->feat_bias, s->lr);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

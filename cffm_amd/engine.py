@@ -1,0 +1,211 @@
+"""Device-side state and step functions of the CFFM hot path: the replacement for the TF session.
+
+``HipEngine`` owns what ``tf.Session`` owned in the reference (CFFM.py:160): the variables and their
+Adagrad accumulators, resident in HBM for the life of the object as torch tensors, plus a per-batch-size
+workspace.  ``predict`` and ``train_step`` are the two ``sess.run`` call shapes (CFFM.py:596, :200); both
+are single calls into libcffm_hip.so, asynchronous on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+from .spec import ADAGRAD_INIT_ACC, CFFMConfig, init_params, param_shapes
+
+# theta member -> reference variable name (reshaped flat, row-major)
+_THETA_MEMBERS = [
+    ('att_W', 'bias_W'), ('att_b', 'bias_b'), ('bias', 'bias'),
+    ('inner_cw', 'inner_layer_conv_weight_0'), ('inner_cb', 'inner_layer_conv_bias_0'),
+    ('inner_dw', 'dense_kernel'), ('inner_db', 'dense_bias'),
+    ('d1_w', 'dense_1_kernel'), ('d1_b', 'dense_1_bias'), ('d2_w', 'dense_2_kernel'), ('d2_b', 'dense_2_bias'),
+    ('lin_w', 'dense_3_kernel'), ('lin_b', 'dense_3_bias'),
+]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HipEngine(object):
+    def __init__(self, cfg, params=None, seed=2021, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise RuntimeError('cffm_amd.HipEngine needs an MI355X (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.lib = hip.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.shape = hip.make_shape(cfg)
+        self.tl = hip.theta_layout(self.shape)
+        self._ws = {}
+        self._host_only = {}
+        if params is None:
+            params = init_params(cfg, seed=seed)
+        n = int(self.tl.n)
+        dev = self.device
+        self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.theta_acc = torch.full((n,), ADAGRAD_INIT_ACC, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        M = cfg.M
+        self.inner = torch.zeros((M, cfg.K), dtype=torch.float32, device=dev)
+        self.outer = torch.zeros((M, cfg.D), dtype=torch.float32, device=dev)
+        self.fbias = torch.zeros((M,), dtype=torch.float32, device=dev)
+        self.inner_acc = torch.full_like(self.inner, ADAGRAD_INIT_ACC)
+        self.outer_acc = torch.full_like(self.outer, ADAGRAD_INIT_ACC)
+        self.fbias_acc = torch.full_like(self.fbias, ADAGRAD_INIT_ACC)
+        self.tables = hip.Tables(self.inner.data_ptr(), self.outer.data_ptr(), self.fbias.data_ptr())
+        self.tables_acc = hip.Tables(self.inner_acc.data_ptr(), self.outer_acc.data_ptr(), self.fbias_acc.data_ptr())
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.load_params(params)
+
+    # ---- named parameters <-> device buffers -------------------------------------------------------
+    def _members(self):
+        out = [(getattr(self.tl, m), name) for m, name in _THETA_MEMBERS]
+        for l in range(self.tl.live):
+            out.append((self.tl.conv_w[l], 'outer_layer_conv_weight_%d' % l))
+            out.append((self.tl.conv_b[l], 'outer_layer_conv_bias_%d' % l))
+        return out
+
+    def load_params(self, params, accs=None):
+        shapes = param_shapes(self.cfg)
+        host = np.zeros(int(self.tl.n), dtype=np.float32)
+        for off, name in self._members():
+            v = np.asarray(params[name], dtype=np.float32).reshape(-1)
+            host[off:off + v.size] = v
+        self.theta.copy_(torch.from_numpy(host))
+        self.inner.copy_(torch.from_numpy(np.asarray(params['inner_embeddings'], dtype=np.float32)))
+        self.outer.copy_(torch.from_numpy(np.asarray(params['outer_embeddings'], dtype=np.float32)))
+        self.fbias.copy_(torch.from_numpy(np.asarray(params['feature_bias'], dtype=np.float32).reshape(-1)))
+        trained = set(n for _, n in self._members()) | {'inner_embeddings', 'outer_embeddings', 'feature_bias'}
+        self._host_only = {k: np.array(params[k], dtype=np.float32) for k in shapes if k not in trained}
+        if accs is not None:
+            ha = np.full(int(self.tl.n), ADAGRAD_INIT_ACC, dtype=np.float32)
+            for off, name in self._members():
+                v = np.asarray(accs[name], dtype=np.float32).reshape(-1)
+                ha[off:off + v.size] = v
+            self.theta_acc.copy_(torch.from_numpy(ha))
+            self.inner_acc.copy_(torch.from_numpy(np.asarray(accs['inner_embeddings'], dtype=np.float32)))
+            self.outer_acc.copy_(torch.from_numpy(np.asarray(accs['outer_embeddings'], dtype=np.float32)))
+            self.fbias_acc.copy_(torch.from_numpy(np.asarray(accs['feature_bias'], dtype=np.float32).reshape(-1)))
+
+    def _export(self, flat, inner, outer, fbias):
+        shapes = param_shapes(self.cfg)
+        host = flat.detach().cpu().numpy()
+        out = {}
+        for off, name in self._members():
+            shp = shapes[name]
+            n = int(np.prod(shp)) if shp else 1
+            out[name] = host[off:off + n].reshape(shp).copy()
+        out['inner_embeddings'] = inner.detach().cpu().numpy().copy()
+        out['outer_embeddings'] = outer.detach().cpu().numpy().copy()
+        out['feature_bias'] = fbias.detach().cpu().numpy().reshape(-1, 1).copy()
+        return out
+
+    def export_params(self):
+        out = self._export(self.theta, self.inner, self.outer, self.fbias)
+        out.update({k: v.copy() for k, v in self._host_only.items()})
+        return out
+
+    def export_accumulators(self):
+        return self._export(self.theta_acc, self.inner_acc, self.outer_acc, self.fbias_acc)
+
+    def export_grad(self):
+        """Dense-parameter gradients of the last backward, by reference variable name."""
+        z = torch.zeros(1, device=self.device)
+        g = self._export(self.grad, z, z, z)
+        for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+            g.pop(k)
+        return g
+
+    # ---- workspace ---------------------------------------------------------------------------------
+    def workspace(self, B):
+        B = int(B)
+        hit = self._ws.get(B)
+        if hit is None:
+            wl = hip.ws_layout(self.shape, B)
+            buf = torch.empty(int(wl.bytes), dtype=torch.uint8, device=self.device)
+            hit = (buf, wl)
+            self._ws[B] = hit
+        return hit
+
+    def ws_tensor(self, B, member, shape, dtype=torch.float32, index=None):
+        """View of one workspace intermediate (for the parity tests)."""
+        buf, wl = self.workspace(B)
+        off = getattr(wl, member)
+        if index is not None:
+            off = off[index]
+        n = int(np.prod(shape))
+        itemsize = 4
+        return buf[int(off):int(off) + n * itemsize].view(dtype).reshape(shape)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ids(ids):
+        if ids.dtype != torch.int32 or not ids.is_contiguous():
+            ids = ids.to(torch.int32).contiguous()
+        return ids
+
+    # ---- the two sess.run call shapes ---------------------------------------------------------------
+    def predict(self, ids):
+        """sess.run(self.out) (CFFM.py:596): int32 ids [B,F] on device -> fp32 [B] on device."""
+        ids = self._ids(ids)
+        B = ids.shape[0]
+        if B == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.device)
+        buf, _ = self.workspace(B)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        hip.check(self.lib.cffm_predict(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
+                                        B, _ptr(buf), _ptr(out), self._stream()))
+        return out
+
+    def train_step(self, ids, y):
+        """sess.run((self.loss, self.optimizer)) (CFFM.py:200).  Returns the loss as a device scalar
+        (no host sync)."""
+        ids = self._ids(ids)
+        y = y.reshape(-1)
+        if y.dtype != torch.float32 or not y.is_contiguous():
+            y = y.to(torch.float32).contiguous()
+        B = ids.shape[0]
+        buf, _ = self.workspace(B)
+        hip.check(self.lib.cffm_train_step(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+                                           _ptr(self.theta), _ptr(self.theta_acc), _ptr(self.grad), _ptr(ids),
+                                           _ptr(y), B, _ptr(buf), _ptr(self.loss_buf), self._stream()))
+        return self.loss_buf
+
+    # ---- halves of the step (multi-GPU path and tests) ---------------------------------------------
+    def forward(self, ids, y=None):
+        ids = self._ids(ids)
+        B = ids.shape[0]
+        buf, _ = self.workspace(B)
+        hip.check(self.lib.cffm_forward(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
+                                        _ptr(y), B, _ptr(buf), self._stream()))
+
+    def backward(self, y, B, B_global=None):
+        buf, _ = self.workspace(B)
+        hip.check(self.lib.cffm_backward(C.byref(self.shape), _ptr(self.theta), _ptr(y), int(B),
+                                         int(B if B_global is None else B_global), _ptr(buf), _ptr(self.grad),
+                                         self._stream()))
+
+    def apply_dense(self):
+        hip.check(self.lib.cffm_dense_adagrad(_ptr(self.theta), _ptr(self.theta_acc), _ptr(self.grad),
+                                              int(self.tl.n), float(self.cfg.lr), self._stream()))
+
+    def apply_sparse(self, ids, dEi, dEo, dfb, B_ws):
+        ids = self._ids(ids.reshape(-1))
+        buf, _ = self.workspace(B_ws)
+        hip.check(self.lib.cffm_sparse_adagrad(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+                                               _ptr(ids), int(ids.numel()), _ptr(dEi), _ptr(dEo), _ptr(dfb),
+                                               _ptr(buf), int(B_ws), self._stream()))
+
+    def gather(self, ids, want_inner=True, want_outer=True, want_bias=True):
+        ids = self._ids(ids)
+        B, F = ids.shape
+        dev = self.device
+        Ei = torch.empty((B, F, self.cfg.K), dtype=torch.float32, device=dev) if want_inner else None
+        Eo = torch.empty((B, F, self.cfg.D), dtype=torch.float32, device=dev) if want_outer else None
+        fb = torch.empty((B, F), dtype=torch.float32, device=dev) if want_bias else None
+        hip.check(self.lib.cffm_gather(C.byref(self.shape), C.byref(self.tables), _ptr(ids), B, _ptr(Ei), _ptr(Eo),
+                                       _ptr(fb), self._stream()))
+        return Ei, Eo, fb

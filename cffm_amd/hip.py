@@ -1,0 +1,123 @@
+"""ctypes binding of libcffm_hip.so (the C ABI declared in include/cffm_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
+
+MAX_LAYERS = 8
+NSLAB = 64
+HEAD_UNITS = 32
+LOSS_IDS = {'square_loss': 0, 'mse': 1, 'mae': 2, 'log_loss': 3}
+
+
+class Shape(C.Structure):
+    _fields_ = [('M', C.c_int32), ('F', C.c_int32), ('K', C.c_int32), ('D', C.c_int32), ('act', C.c_int32),
+                ('linear_att', C.c_int32), ('inner_conv', C.c_int32), ('outer_conv', C.c_int32),
+                ('loss', C.c_int32), ('lamda_att', C.c_float), ('beta_outer', C.c_float), ('lr', C.c_float)]
+
+
+class ThetaLayout(C.Structure):
+    _fields_ = [('n', C.c_int64), ('att_W', C.c_int64), ('att_b', C.c_int64), ('bias', C.c_int64),
+                ('inner_cw', C.c_int64), ('inner_cb', C.c_int64), ('inner_dw', C.c_int64), ('inner_db', C.c_int64),
+                ('conv_w', C.c_int64 * MAX_LAYERS), ('conv_b', C.c_int64 * MAX_LAYERS),
+                ('d1_w', C.c_int64), ('d1_b', C.c_int64), ('d2_w', C.c_int64), ('d2_b', C.c_int64),
+                ('lin_w', C.c_int64), ('lin_b', C.c_int64),
+                ('P', C.c_int32), ('Pp', C.c_int32), ('Lc', C.c_int32), ('live', C.c_int32)]
+
+
+class WsLayout(C.Structure):
+    _fields_ = [('bytes', C.c_int64), ('Ei', C.c_int64), ('Eo', C.c_int64), ('fb', C.c_int64),
+                ('inner_out', C.c_int64), ('C', C.c_int64 * MAX_LAYERS),
+                ('t1', C.c_int64), ('h1', C.c_int64), ('att', C.c_int64), ('out', C.c_int64),
+                ('sqerr', C.c_int64), ('scalars', C.c_int64), ('dout', C.c_int64), ('dt1', C.c_int64),
+                ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
+                ('gpart', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
+                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64)]
+
+
+class Tables(C.Structure):
+    _fields_ = [('inner_emb', C.c_void_p), ('outer_emb', C.c_void_p), ('feat_bias', C.c_void_p)]
+
+
+_P = C.c_void_p
+_SH = C.POINTER(Shape)
+_TB = C.POINTER(Tables)
+
+# name -> (restype, argtypes); every symbol include/cffm_hip.h declares
+PROTOTYPES = {
+    'cffm_abi_version': (C.c_int, []),
+    'cffm_error_string': (C.c_char_p, [C.c_int]),
+    'cffm_theta_layout': (C.c_int, [_SH, C.POINTER(ThetaLayout)]),
+    'cffm_ws_layout': (C.c_int, [_SH, C.c_int32, C.POINTER(WsLayout)]),
+    'cffm_gather': (C.c_int, [_SH, _TB, _P, C.c_int32, _P, _P, _P, _P]),
+    'cffm_inner_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
+    'cffm_inner_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
+    'cffm_outer_conv0_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
+    'cffm_outer_conv0_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
+    'cffm_conv_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int32, _P]),
+    'cffm_conv_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int32, _P]),
+    'cffm_head_fwd': (C.c_int, [_SH, _P, _P, _P, C.c_int32, _P]),
+    'cffm_head_bwd': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P]),
+    'cffm_reduce_slabs': (C.c_int, [_SH, _P, _P, _P]),
+    'cffm_dense_adagrad': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    'cffm_sparse_adagrad': (C.c_int, [_SH, _TB, _TB, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),
+    'cffm_predict': (C.c_int, [_SH, _TB, _P, _P, C.c_int32, _P, _P, _P]),
+    'cffm_forward': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, _P, _P]),
+    'cffm_backward': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    'cffm_train_step': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcffm_hip.so once.  torch must be imported first so that the HIP runtime the library
+    binds to (SONAME libamdhip64.so.7) is the one torch already loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('cffm_amd: %s is missing - build it with `make` or __graft_entry__.build(); '
+                           'there is no CPU fallback' % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 / libhsa-runtime64 into the process)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cffm_abi_version() != 1:
+        raise RuntimeError('cffm_amd: ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cffm_error_string(rc)
+        raise RuntimeError('libcffm_hip: error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+
+def make_shape(cfg):
+    if cfg.loss_type not in LOSS_IDS:
+        raise ValueError('loss_type %r is not supported by the HIP path' % (cfg.loss_type,))
+    if cfg.loss_type == 'square_loss' and cfg.lamda_bilinear > 0:
+        raise ValueError('square_loss with lamda > 0 is not supported by the HIP path yet')
+    return Shape(M=cfg.M, F=cfg.F, K=cfg.K, D=cfg.D, act=cfg.act_id, linear_att=cfg.linear_att,
+                 inner_conv=cfg.inner_conv, outer_conv=cfg.outer_conv, loss=LOSS_IDS[cfg.loss_type],
+                 lamda_att=cfg.lamda_att, beta_outer=float(cfg.beta_outer), lr=cfg.lr)
+
+
+def theta_layout(shape):
+    tl = ThetaLayout()
+    check(load().cffm_theta_layout(C.byref(shape), C.byref(tl)))
+    return tl
+
+
+def ws_layout(shape, B):
+    wl = WsLayout()
+    check(load().cffm_ws_layout(C.byref(shape), int(B), C.byref(wl)))
+    return wl

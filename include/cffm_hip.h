@@ -1,0 +1,170 @@
+/*
+ * cffm_hip.h - C ABI of libcffm_hip.so: the CFFM convolutional feature-interaction hot path on
+ * MI355X (gfx950).
+ *
+ * The reference (Anony-CFFM/CFFM) has no FFI: its boundary between host loop and tensor runtime is
+ * the pair of TensorFlow session calls
+ *     loss, opt = sess.run((self.loss, self.optimizer), feed_dict)      CFFM.py:200   (train step)
+ *     batch_out = sess.run((self.out), feed_dict)                       CFFM.py:596   (predict)
+ * over the graph built by create_inference_convolutional_feature_interaction_FM (CFFM.py:296-453),
+ * create_loss (CFFM.py:486-514) and create_optimizer (CFFM.py:517-529).  The entry points below are
+ * what a binding for that seam would call instead; each one cites the graph lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (torch tensors in this repo) unless
+ *     the name ends in _host; nothing is allocated or freed inside the library;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*; NULL = default stream);
+ *   - return value: 0 on success, otherwise a hipError_t (or CFFM_ERR_*) - cffm_error_string() gives
+ *     the text; no global mutable state, safe from one host thread per device;
+ *   - all arithmetic is fp32, ids are int32 (CFFM.py:232-235).
+ */
+#ifndef CFFM_HIP_H
+#define CFFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFFM_ABI_VERSION 1
+#define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
+#define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
+#define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
+#define CFFM_NSLAB 64              /* split-K partial slabs of every dense-gradient producer     */
+
+#define CFFM_ERR_BAD_SHAPE 10001
+#define CFFM_ERR_UNSUPPORTED 10002
+
+/* activation ids, CFFM.py:132-141 */
+enum { CFFM_ACT_RELU = 0, CFFM_ACT_PRELU = 1, CFFM_ACT_ELU = 2, CFFM_ACT_SELU = 3, CFFM_ACT_GELU = 4 };
+/* loss ids, CFFM.py:486-514 (square_loss with lamda == 0 is the README default) */
+enum { CFFM_LOSS_SQUARE_RMSE = 0, CFFM_LOSS_MSE = 1, CFFM_LOSS_MAE = 2, CFFM_LOSS_LOG = 3 };
+
+typedef struct cffm_shape {
+    int32_t M;            /* features_M                                   CFFM.py:110            */
+    int32_t F;            /* num_field                                    CFFM.py:119            */
+    int32_t K;            /* inner_dims (even)                            CFFM.py:105            */
+    int32_t D;            /* outer_dims (power of two >= 4)               CFFM.py:106            */
+    int32_t act;          /* CFFM_ACT_*                                   CFFM.py:132-141        */
+    int32_t linear_att;   /* 1: attention first-order term, 0: plain sum  CFFM.py:423-446        */
+    int32_t inner_conv;   /* CFFM.py:301                                                         */
+    int32_t outer_conv;   /* CFFM.py:348                                                         */
+    int32_t loss;         /* CFFM_LOSS_*                                                         */
+    float lamda_att;      /* CFFM.py:434                                                         */
+    float beta_outer;     /* CFFM.py:414                                                         */
+    float lr;             /* CFFM.py:523                                                         */
+} cffm_shape_t;
+
+/* Offsets (in floats) of the trained dense parameters inside ONE flat fp32 buffer "theta".  The same
+ * layout is used for the Adagrad accumulators and for the gradient buffer.  Untrained variables of
+ * the reference (outer_W/outer_b, CFFM.py:271-272; the dead last conv layer, CFFM.py:394-396) are not
+ * part of theta - the host keeps them only for the '#params' log line. */
+typedef struct cffm_theta_layout {
+    int64_t n;                              /* total floats                                        */
+    int64_t att_W, att_b;                   /* bias_W [F,F], bias_b [F]          CFFM.py:281-282   */
+    int64_t bias;                           /* scalar                            CFFM.py:284       */
+    int64_t inner_cw, inner_cb;             /* [2 taps][2 ch], [2]               CFFM.py:323       */
+    int64_t inner_dw, inner_db;             /* dense [P*K], [1]                  CFFM.py:339       */
+    int64_t conv_w[CFFM_MAX_LAYERS];        /* HWIO [2,2,P,P] = [4P][P]          CFFM.py:375-377   */
+    int64_t conv_b[CFFM_MAX_LAYERS];        /* [P]                                                 */
+    int64_t d1_w, d1_b;                     /* [2D-2][32], [32]                  CFFM.py:409       */
+    int64_t d2_w, d2_b;                     /* [32], [1]                         CFFM.py:410       */
+    int64_t lin_w, lin_b;                   /* [F], [1]                          CFFM.py:441       */
+    int32_t P, Pp, Lc, live;                /* pairs, pairs padded to 16, log2(D), Lc-1            */
+} cffm_theta_layout_t;
+
+/* Byte offsets of every intermediate inside the caller-provided workspace for a batch of B rows.
+ * Exposed so that the parity tests can read each tensor back and compare it with the oracle. */
+typedef struct cffm_ws_layout {
+    int64_t bytes;
+    int64_t Ei, Eo, fb;                     /* gathered rows [B,F,K] [B,F,D] [B,F]                 */
+    int64_t inner_out;                      /* [B]                                                 */
+    int64_t C[CFFM_MAX_LAYERS];             /* relu(conv_l + b_l)  [B,S_l,S_l,Pp], S_l = D>>(l+1)  */
+    int64_t t1, h1, att, out;               /* [B,2D-2] [B,32] [B,F] [B]                           */
+    int64_t sqerr;                          /* per-example loss term [B]                           */
+    int64_t scalars;                        /* [0]=sum of loss terms (local) [1]=loss [2]=dscale [3]=sum used */
+    int64_t dout, dt1;                      /* [B], [B,2D-2]                                       */
+    int64_t dC[CFFM_MAX_LAYERS];            /* grad wrt C_l, same shape as C_l                     */
+    int64_t dEi, dEo, dfb;                  /* IndexedSlices values [B,F,K] [B,F,D] [B,F]          */
+    int64_t gpart;                          /* [CFFM_NSLAB][theta.n] split-K partial gradients     */
+    int64_t sort_keys, sort_vals;           /* int32 [B*F] each (sorted ids, source slots)         */
+    int64_t sort_tmp;                       /* radix sort scratch                                  */
+    int64_t sort_tmp_bytes;
+} cffm_ws_layout_t;
+
+typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
+    float *inner_emb;                       /* [M,K]  inner_embeddings  CFFM.py:257                */
+    float *outer_emb;                       /* [M,D]  outer_embeddings  CFFM.py:264                */
+    float *feat_bias;                       /* [M]    feature_bias      CFFM.py:276                */
+} cffm_tables_t;
+
+/* ---- layout queries (host only, no GPU needed) -------------------------------------------------- */
+int cffm_abi_version(void);
+const char *cffm_error_string(int err);
+int cffm_theta_layout(const cffm_shape_t *s, cffm_theta_layout_t *out);
+int cffm_ws_layout(const cffm_shape_t *s, int32_t B, cffm_ws_layout_t *out);
+
+/* ---- stage entry points ------------------------------------------------------------------------ */
+/* tf.nn.embedding_lookup x3 (CFFM.py:303, :354, :422): ids int32 [B*F] -> Ei [B,F,K], Eo [B,F,D],
+ * fb [B,F].  Any of the three outputs may be NULL to skip that table. */
+int cffm_gather(const cffm_shape_t *s, const cffm_tables_t *t, const int32_t *ids, int32_t B,
+                float *Ei, float *Eo, float *fb, void *stream);
+
+/* inner branch CFFM.py:304-343 on gathered rows: ws.Ei -> ws.inner_out */
+int cffm_inner_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
+/* its gradient: ws.dout, ws.Ei -> ws.dEi, gpart slabs of inner_cw/inner_cb/inner_dw/inner_db */
+int cffm_inner_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
+
+/* outer product fused with conv layer 0 (CFFM.py:355-367 + :385-386 for i = 0): ws.Eo -> ws.C[0] */
+int cffm_outer_conv0_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
+/* ws.dC[0], ws.dt1, ws.Eo -> ws.dEo, gpart slabs of conv_w[0]/conv_b[0] */
+int cffm_outer_conv0_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
+
+/* conv layer l >= 1 (CFFM.py:385-387): ws.C[l-1] -> ws.C[l] */
+int cffm_conv_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, int32_t layer, void *stream);
+/* ws.dC[l], ws.C[l-1], ws.dt1 -> ws.dC[l-1], gpart slabs of conv_w[l]/conv_b[l] */
+int cffm_conv_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, int32_t layer, void *stream);
+
+/* sum pooling + concat + dense heads + first-order term + add_n (CFFM.py:381, :390-396, :409-453):
+ * ws.C[*], ws.Eo, ws.fb, ws.inner_out -> ws.t1, ws.h1, ws.att, ws.out; when y != NULL also ws.sqerr and
+ * scalars[0] = sum of per-example loss terms over the B local rows. */
+int cffm_head_fwd(const cffm_shape_t *s, const float *theta, void *ws, const float *y, int32_t B, void *stream);
+/* loss gradient (CFFM.py:493) and the head's backward: ws.out, y, scalars[3] (the loss-term sum over
+ * the GLOBAL batch of B_global rows) -> ws.dout, ws.dt1, ws.dfb, ws.dC[live-1], gpart slabs of the
+ * head parameters, scalars[1] = loss. */
+int cffm_head_bwd(const cffm_shape_t *s, const float *theta, void *ws, const float *y, int32_t B,
+                  int64_t B_global, void *stream);
+
+/* sum the CFFM_NSLAB slabs of ws.gpart in slab order -> grad [theta.n] (bitwise reproducible) */
+int cffm_reduce_slabs(const cffm_shape_t *s, void *ws, float *grad, void *stream);
+
+/* tf.train.AdagradOptimizer (CFFM.py:523-524), dense: acc += g*g; v -= lr*g/sqrt(acc) over n floats */
+int cffm_dense_adagrad(float *theta, float *acc, const float *grad, int64_t n, float lr, void *stream);
+/* sparse: ids int32 [n_rows] with row gradients dEi [n_rows,K], dEo [n_rows,D], dfb [n_rows]; duplicate
+ * ids are summed FIRST (in slot order), then one update per distinct row; other rows untouched. */
+int cffm_sparse_adagrad(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *acc,
+                        const int32_t *ids, int64_t n_rows, const float *dEi, const float *dEo,
+                        const float *dfb, void *ws, int32_t B_ws, void *stream);
+
+/* ---- composites: what CFFM.evaluate / CFFM.train call in place of the two sess.run()s ------------- */
+/* sess.run(self.out) CFFM.py:596: ids [B,F] -> out [B] (also left in ws.out) */
+int cffm_predict(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids,
+                 int32_t B, void *ws, float *out, void *stream);
+/* forward half of a train step, through the per-example loss terms */
+int cffm_forward(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids,
+                 const float *y, int32_t B, void *ws, void *stream);
+/* backward half: needs scalars[3] = global loss-term sum (cffm_train_step copies scalars[0] there) */
+int cffm_backward(const cffm_shape_t *s, const float *theta, const float *y, int32_t B, int64_t B_global,
+                  void *ws, float *grad, void *stream);
+/* sess.run((self.loss, self.optimizer)) CFFM.py:200: one fused forward + backward + Adagrad update of
+ * theta/tables (and their accumulators) in place; loss (device scalar, may be NULL) receives the loss. */
+int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,
+                    float *theta, float *theta_acc, float *grad, const int32_t *ids, const float *y,
+                    int32_t B, void *ws, float *loss, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFFM_HIP_H */

@@ -301,6 +301,8 @@ def backward(p, cache, dout, cfg):
             dpools.append(dt1[:, off:off + wdt])
             off += wdt
         dA = None                                                       # grad wrt A_l (post-activation)
+        g['_dt1'] = dt1
+        g['_dC'] = {}
         for l in range(Lc - 2, -1, -1):
             S = D >> (l + 1)
             dAl = np.broadcast_to(dpools[l + 1][:, :, None, None], (B, S, S, P)).astype(dt)
@@ -308,6 +310,7 @@ def backward(p, cache, dout, cfg):
                 dAl = dAl + dA
             r = cache['rs'][l]
             dz = dAl * act_grad(r, kind) * (r > 0)
+            g['_dC'][l] = dz
             W = p['outer_layer_conv_weight_%d' % l].reshape(4 * P, P)
             patches = cache['patches'][l]
             g['outer_layer_conv_bias_%d' % l] = dz.sum(axis=(0, 1, 2))
@@ -374,15 +377,18 @@ def init_accumulators(p):
     return {k: np.full_like(v, ADAGRAD_INIT_ACC) for k, v in p.items()}
 
 
-def train_step(p, acc, X, y, cfg):
+def train_step(p, acc, X, y, cfg, cache_hook=None):
     """One ``sess.run((loss, optimizer))`` (CFFM.py:200): forward, loss, backward, Adagrad.
-    Mutates p and acc in place; returns (loss, out_before_update)."""
+    Mutates p and acc in place; returns (loss, out_before_update).  ``cache_hook(cache)`` lets a test
+    adopt the device's relu decisions for pre-activations that sit on the kink (see tests)."""
     out, cache = forward(p, X, cfg)
+    if cache_hook is not None:
+        cache_hook(cache)
     L, dout = loss_and_grad(out, y.astype(out.dtype), cfg, p)
     g = backward(p, cache, dout.astype(out.dtype), cfg)
     lr = cfg.lr
     for name, grad in g.items():
-        if name.startswith('d_'):
+        if name.startswith('d_') or name.startswith('_'):
             continue
         if name == 'bias':
             a = acc['bias'] + grad * grad
