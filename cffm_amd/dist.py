@@ -1,0 +1,122 @@
+"""Multi-GPU training step: batch-sharded data parallel, one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-device only (no distributed code anywhere in /root/reference), so this is new
+design.  Examples are independent in the forward pass; the only couplings are the loss normaliser (a mean
+over the GLOBAL batch, CFFM.py:493) and the parameter gradients:
+
+  1. local forward, per-example loss terms                      (no communication)
+  2. all-reduce of ONE scalar: the sum of loss terms            -> global loss L and dL/dout = (out-y)/(Bg*L)
+  3. local backward with that normaliser                        (no communication)
+  4. all-reduce (sum) of the flat dense gradient                (36 K floats at frappe, 5 M at F=32)
+  5. sparse tables, two modes:
+       replicated (default while the tables fit one GPU):  all-gather of (ids, row gradients); every rank then
+           runs the same sorted segment-sum + Adagrad over the Bg*F rows, so the replicas stay bit-identical;
+       row-sharded (``ShardedTables``, vocabulary beyond one GPU's HBM): ids all-to-all to the owner
+           (row r lives on rank r % G), owners gather and send rows back, row gradients return by all-to-all and
+           the owner applies the duplicates-summed-first update locally.
+
+``compute`` is any object with the HipEngine step-half interface (forward / backward / apply_dense /
+apply_sparse + the tensors named below); the CPU tests plug the oracle in there, the product uses HipEngine.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelStep(object):
+    def __init__(self, compute, group=None):
+        self.c = compute
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _all_gather_cat(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts, dim=0)
+
+    def train_step(self, ids, y):
+        """ids int32 [B,F], y fp32 [B]: this rank's shard of the global batch (same B on every rank).
+        Returns the global loss as a device scalar tensor."""
+        c = self.c
+        B = ids.shape[0]
+        Bg = B * self.world
+        c.forward(ids, y)
+        s = c.loss_sum_local(B).clone()                       # [1] sum of per-example loss terms
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        c.set_loss_sum_global(B, s)
+        c.backward(y, B, Bg)
+        dist.all_reduce(c.grad, op=dist.ReduceOp.SUM, group=self.group)
+        c.apply_dense()
+        dEi, dEo, dfb = c.row_grads(B)
+        ids_all = self._all_gather_cat(ids.reshape(-1))
+        dEi_all = self._all_gather_cat(dEi.reshape(B * ids.shape[1], -1)) if dEi is not None else None
+        dEo_all = self._all_gather_cat(dEo.reshape(B * ids.shape[1], -1)) if dEo is not None else None
+        dfb_all = self._all_gather_cat(dfb.reshape(-1))
+        c.apply_sparse(ids_all, dEi_all, dEo_all, dfb_all, Bg)
+        return c.loss_value(B)
+
+
+def shard_of(ids, world):
+    """Owner rank and local row of every id under the r -> (r % G, r // G) row sharding."""
+    return ids % world, ids // world
+
+
+def route_ids(ids_flat, world):
+    """Sort the lookups of one rank by owner: returns (perm, counts) with ids_flat[perm] grouped by owner
+    rank in rank order and counts[g] lookups going to rank g.  Pure index arithmetic (no collective)."""
+    owner = ids_flat % world
+    perm = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=world)
+    return perm, counts
+
+
+class ShardedTables(object):
+    """Row-sharded embedding tables: row r of every table lives on rank r % G at local index r // G.
+    ``lookup`` and ``push_grads`` are the two exchange steps of a training step; both are all-to-all over
+    the lookups of the batch, so their volume scales with B*F, not with the vocabulary."""
+
+    def __init__(self, local_tables, group=None):
+        # local_tables: dict name -> tensor [M_local, dim] holding rows rank, rank+G, rank+2G, ...
+        self.t = local_tables
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._route = None
+
+    def _exchange_counts(self, counts):
+        recv = torch.empty_like(counts)
+        dist.all_to_all_single(recv, counts, group=self.group)
+        return recv
+
+    def lookup(self, ids_flat):
+        """ids_flat int64/int32 [n] global ids -> dict name -> [n, dim] rows, in the caller's order."""
+        world = self.world
+        perm, send_counts = route_ids(ids_flat.long(), world)
+        recv_counts = self._exchange_counts(send_counts)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        req = torch.empty(sum(rc), dtype=torch.long, device=ids_flat.device)
+        dist.all_to_all_single(req, ids_flat.long()[perm].contiguous(), rc, sc, group=self.group)
+        local_rows = req // world
+        out = {}
+        for name, tab in self.t.items():
+            rows = tab[local_rows].contiguous()
+            back = torch.empty((ids_flat.numel(),) + tuple(tab.shape[1:]), dtype=tab.dtype, device=tab.device)
+            dist.all_to_all_single(back, rows, sc, rc, group=self.group)
+            res = torch.empty_like(back)
+            res[perm] = back
+            out[name] = res
+        self._route = (perm, sc, rc, local_rows)
+        return out
+
+    def push_grads(self, row_grads):
+        """row_grads: dict name -> [n, dim] gradients in the order of the last lookup.  Returns
+        (local_rows [m], dict name -> [m, dim]) : what this rank's owner-side sparse update consumes."""
+        perm, sc, rc, local_rows = self._route
+        out = {}
+        for name, g in row_grads.items():
+            send = g[perm].contiguous()
+            recv = torch.empty((sum(rc),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.all_to_all_single(recv, send, rc, sc, group=self.group)
+            out[name] = recv
+        return local_rows, out

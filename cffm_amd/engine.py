@@ -199,6 +199,22 @@ class HipEngine(object):
                                                _ptr(ids), int(ids.numel()), _ptr(dEi), _ptr(dEo), _ptr(dfb),
                                                _ptr(buf), int(B_ws), self._stream()))
 
+    # ---- views the data-parallel step needs (cffm_amd/dist.py) ----------------------------------------
+    def loss_sum_local(self, B):
+        return self.ws_tensor(B, 'scalars', (16,))[0:1]
+
+    def set_loss_sum_global(self, B, s):
+        self.ws_tensor(B, 'scalars', (16,))[3:4].copy_(s)
+
+    def loss_value(self, B):
+        return self.ws_tensor(B, 'scalars', (16,))[1:2]
+
+    def row_grads(self, B):
+        F = self.cfg.F
+        dEi = self.ws_tensor(B, 'dEi', (B, F, self.cfg.K)) if self.cfg.inner_conv else None
+        dEo = self.ws_tensor(B, 'dEo', (B, F, self.cfg.D)) if self.cfg.outer_conv else None
+        return dEi, dEo, self.ws_tensor(B, 'dfb', (B, F))
+
     def gather(self, ids, want_inner=True, want_outer=True, want_bias=True):
         ids = self._ids(ids)
         B, F = ids.shape
