@@ -1,0 +1,306 @@
+"""Drop-in for the reference's CFFM.py surface on top of the HIP engine.
+
+Same command line (24 flags, CFFM.py:24-78), same constructor signature (CFFM.py:98-101), same
+``train(data)`` / ``evaluate(data) -> (RMSE, R2)`` methods, same public metric lists and helper methods,
+same log line formats (CFFM.py:174-179, :218-221, :553, :658-664, :684-695).  What is different underneath:
+
+* the TensorFlow session is replaced by ``cffm_amd.engine.HipEngine`` (hand-written gfx950 kernels behind
+  the C ABI of include/cffm_hip.h); there is no CPU fallback;
+* the libfm splits are packed once into int32/fp32 tensors resident in HBM; the reference's per-sample
+  Python batchers (CFFM.py:560-581, :617-629) reduce to slicing those tensors.  The batch COMPOSITION rule
+  is the reference's: a contiguous block from ``np.random.randint(0, N - batch_size)`` after a per-epoch
+  ``sklearn.utils.shuffle(..., random_state=2021)`` (quirk Q9), ordered blocks with a ragged last one in
+  ``evaluate``;
+* quirks that crash the reference are not reproduced: ``--tensorboard 1`` (Q6) is accepted and ignored with
+  a warning, ``--pretrain 1`` (Q7) restores THIS model's tensors, no CUDA_VISIBLE_DEVICES pin (Q8).
+"""
+import argparse
+import logging
+import math
+import os
+from time import time
+
+import numpy as np
+from sklearn.metrics import mean_squared_error, r2_score
+from sklearn.utils import shuffle
+
+from . import LoadData as DATA
+from .spec import CFFMConfig, logged_param_count
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Run CFFM.")
+    add = parser.add_argument
+    add('--path', nargs='?', default='data/', help='Input data path.')
+    add('--dataset', nargs='?', default='frappe', help='Choose a dataset.')
+    add('--epoch', type=int, default=50, help='Number of epochs.')
+    add('--pretrain', type=int, default=0,
+        help='flag for pretrain. 1: initialize from pretrain; 0: randomly initialize; -1: save the model to pretrain file')
+    add('--batch_size', type=int, default=1024, help='Batch size.')
+    add('--inner_dims', type=int, default=32, help='Number of inner dimensions.')
+    add('--outer_dims', type=int, default=32, help='Number of outer dimensions.')
+    add('--lamda', type=float, default=0, help='Regularizer for bilinear part.')
+    add('--keep', nargs='?', default='[1.0,1.0]', help='Keep probility (1-dropout) of each layer (parsed, unused).')
+    add('--lr', type=float, default=0.05, help='Learning rate.')
+    add('--loss_type', nargs='?', default='square_loss',
+        help='Specify a loss type (square_loss or log_loss or mse or mae).')
+    add('--optimizer', nargs='?', default='AdagradOptimizer', help='Specify an optimizer type (AdagradOptimizer).')
+    add('--verbose', type=int, default=1, help='Show the results per X epochs (0, 1 ... any positive integer)')
+    add('--batch_norm', type=int, default=0, help='Parsed, unused (as in the reference graph).')
+    add('--tensorboard', type=int, default=0, help='Accepted and ignored (the reference crashes with 1).')
+    add('--num_field', type=int, default=3,
+        help='Valid dimension of the dataset. (e.g. frappe=10, ml-tag=3, book-crossing=6)')
+    add('--linear_att', type=int, default=1, help='Linear attention part (0 disable or 1 enable)')
+    add('--att_dim', type=int, default=0, help='Dimension of linear attention (0 is the same as num_field)')
+    add('--lamda_att', type=float, default=1.0, help='Softmax temperature of the linear attention part')
+    add('--inner_conv', type=int, default=1, help='Inner convolution part (0 disable or 1 enable)')
+    add('--gamma_inner', type=int, default=1.0, help='Parsed, unused (as in the reference graph).')
+    add('--outer_conv', type=int, default=1, help='Outer convolution part (0 disable or 1 enable)')
+    add('--beta_outer', type=int, default=1.0, help='Weight of the outer convolution component')
+    add('--activation', nargs='?', default='relu', help='Activation function (relu, prelu, elu, selu, gelu)')
+    return parser.parse_args(argv)
+
+
+def configure_logging(logFilename):
+    logging.basicConfig(level=logging.DEBUG, format='%(asctime)s %(filename)s:%(message)s',
+                        datefmt='%Y-%m-%d %A %H:%M:%S', filename=logFilename, filemode='a')
+    console = logging.StreamHandler()
+    console.setLevel(logging.INFO)
+    console.setFormatter(logging.Formatter('%(asctime)s %(filename)s:%(message)s'))
+    logging.getLogger().addHandler(console)
+
+
+class CFFM(object):
+    def __init__(self, features_M, pretrain_flag, save_file, inner_dims, outer_dims, loss_type, epoch, batch_size,
+                 learning_rate, lamda_bilinear, keep, optimizer_type, batch_norm, verbose, tensorboard, num_field,
+                 linear_att, att_dim, lamda_att, inner_conv, gamma_inner, outer_conv, beta_outer,
+                 activation_function, random_seed=2021):
+        self.batch_size = batch_size
+        self.learning_rate = learning_rate
+        self.inner_dims = inner_dims
+        self.outer_dims = outer_dims
+        self.pretrain_flag = pretrain_flag
+        self.save_file = save_file
+        self.loss_type = loss_type
+        self.features_M = features_M
+        self.lamda_bilinear = lamda_bilinear
+        self.keep = keep
+        self.epoch = epoch
+        self.random_seed = random_seed
+        self.optimizer_type = optimizer_type
+        self.batch_norm = batch_norm
+        self.verbose = verbose
+        self.tensorboard = tensorboard
+        self.num_field = num_field
+        self.linear_att = linear_att
+        self.att_dim = num_field if att_dim == 0 else att_dim
+        if self.linear_att == 1 and self.att_dim != num_field:
+            # the reference's matmul [B,F] x [att_dim,att_dim] (CFFM.py:432) only type-checks for att_dim == F
+            raise ValueError('att_dim must equal num_field (or be 0)')
+        self.lamda_att = lamda_att
+        self.inner_conv = inner_conv
+        self.gamma_inner = gamma_inner
+        self.outer_conv = outer_conv
+        self.beta_outer = beta_outer
+        self.num_interactions = int(self.num_field * (self.num_field - 1) / 2)
+        self.activation_function = activation_function
+        if optimizer_type != 'AdagradOptimizer':
+            raise NotImplementedError('only AdagradOptimizer (the reference default, CFFM.py:48) runs on the HIP path')
+        if tensorboard > 0:
+            logging.warning('--tensorboard is accepted and ignored (it crashes the reference, CFFM.py:194-196)')
+        self.config = CFFMConfig(M=features_M, F=num_field, K=inner_dims, D=outer_dims, activation=activation_function,
+                                 lamda_att=lamda_att, beta_outer=beta_outer, linear_att=linear_att,
+                                 inner_conv=inner_conv, outer_conv=outer_conv, loss_type=loss_type,
+                                 lamda_bilinear=lamda_bilinear, lr=learning_rate)
+        self.create_save_folder(save_file)
+        self.train_rmse, self.valid_rmse, self.test_rmse = [], [], []
+        self.train_r2, self.valid_r2, self.test_r2 = [], [], []
+        self.engine = None
+        self._packed = {}
+        self.examples_per_sec = []
+
+    # ---- engine / data residency -----------------------------------------------------------------------
+    def build_graph(self):
+        """Creates the device state (the reference builds the TF graph here, CFFM.py:531-541)."""
+        from .engine import HipEngine
+        self.engine = HipEngine(self.config, seed=self.random_seed)
+        if self.pretrain_flag > 0:
+            self.load(self.save_file)
+        return self.engine
+
+    def _device_split(self, data):
+        """{'X': lists, 'Y': list} -> (ids int32 [N,F], y fp32 [N]) in HBM, packed once per split object."""
+        import torch
+        key = id(data)
+        hit = self._packed.get(key)
+        if hit is not None and hit[2] is data['X']:
+            return hit[0], hit[1]
+        X, Y = DATA.LoadData.packed(data)
+        if X.shape[1] != self.num_field:
+            raise ValueError('rows have %d ids, --num_field is %d' % (X.shape[1], self.num_field))
+        dev = self.engine.device
+        ids, y = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
+        self._packed[key] = (ids, y, data['X'])
+        return ids, y
+
+    # ---- training loop (CFFM.py:157-228) -------------------------------------------------------------
+    def train(self, data):
+        import torch
+        if self.engine is None:
+            self.build_graph()
+        eng = self.engine
+        self.calculate_parameters()
+        if self.verbose > 0:
+            t2 = time()
+            init_train_rmse, init_train_r2 = self.evaluate(data.Train_data)
+            init_valid_rmse, init_validation_r2 = self.evaluate(data.Validation_data)
+            init_test_rmse, init_test_r2 = self.evaluate(data.Test_data)
+            logging.info(("Init_RMSE: train=%.4f,validation=%.4f,test=%.4f | Init_R2: train=%.4f,validation=%.4f,"
+                          "test=%.4f [%.1f s] " % (init_train_rmse, init_valid_rmse, init_test_rmse, init_train_r2,
+                                                  init_validation_r2, init_test_r2, time() - t2)))
+        ids, y = self._device_split(data.Train_data)
+        n = ids.shape[0]
+        for epoch in range(self.epoch):
+            t1 = time()
+            # shuffle_in_unison_scary: the same seeded permutation is applied to the CURRENT order every epoch
+            perm = shuffle(np.arange(n), random_state=self.random_seed)
+            pt = torch.from_numpy(perm).to(ids.device)
+            ids, y = ids[pt].contiguous(), y[pt].contiguous()
+            total_batch = int(n / self.batch_size)
+            for _ in range(total_batch):
+                start = np.random.randint(0, n - self.batch_size)        # CFFM.py:561 (unseeded, as the reference)
+                eng.train_step(ids[start:start + self.batch_size], y[start:start + self.batch_size])
+            torch.cuda.synchronize()
+            t2 = time()
+            self.examples_per_sec.append(total_batch * self.batch_size / max(t2 - t1, 1e-9))
+            # keep the caller's lists consistent with what the reference leaves behind (shuffled in place)
+            self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'])
+            train_rmse, train_r2 = self.evaluate(data.Train_data)
+            valid_rmse, valid_r2 = self.evaluate(data.Validation_data)
+            test_rmse, test_r2 = self.evaluate(data.Test_data)
+            self.train_rmse.append(train_rmse)
+            self.valid_rmse.append(valid_rmse)
+            self.test_rmse.append(test_rmse)
+            self.train_r2.append(train_r2)
+            self.valid_r2.append(valid_r2)
+            self.test_r2.append(test_r2)
+            if self.verbose > 0 and epoch % self.verbose == 0:
+                logging.info(("Epoch %d [%.1f s] RMSE: train=%.4f,validation=%.4f,Test=%.4f | R2: train=%.4f,"
+                              "validation=%.4f,Test=%.4f [%.1f s]" % (epoch + 1, t2 - t1, train_rmse, valid_rmse,
+                                                                      test_rmse, train_r2, valid_r2, test_r2,
+                                                                      time() - t2)))
+                logging.info("Epoch %d throughput: %.0f training examples/s" % (epoch + 1, self.examples_per_sec[-1]))
+            if self.eva_termination(self.valid_rmse):
+                break
+            if self.pretrain_flag < 0:
+                logging.info("Save model to file as pretrain.")
+                self.save(self.save_file)
+
+    # ---- evaluation (CFFM.py:583-615) ------------------------------------------------------------------
+    def evaluate(self, data):
+        import torch
+        if self.engine is None:
+            self.build_graph()
+        ids, y = self._device_split(data)
+        num_example = ids.shape[0]
+        outs = []
+        for s in range(0, num_example, self.batch_size):          # ordered blocks, ragged last one
+            outs.append(self.engine.predict(ids[s:s + self.batch_size]))
+        y_pred = torch.cat(outs).cpu().numpy().astype(np.float64) if outs else np.zeros((0,))
+        y_true = y.cpu().numpy().astype(np.float64)               # same (possibly shuffled) order as ids
+        predictions_bounded = np.maximum(y_pred, np.ones(num_example) * min(y_true))
+        predictions_bounded = np.minimum(predictions_bounded, np.ones(num_example) * max(y_true))
+        RMSE = math.sqrt(mean_squared_error(y_true, predictions_bounded))
+        R2 = r2_score(y_true, predictions_bounded)
+        return RMSE, R2
+
+    # ---- host-side helpers with the reference's list semantics (CFFM.py:556-635) -------------------------
+    def shuffle_in_unison_scary(self, x, y):
+        x_, y_ = shuffle(x, y, random_state=self.random_seed)
+        return x_, y_
+
+    def get_random_block_from_data(self, data, batch_size):
+        """A block from a random start, filled forward over rows as long as the start row, then BACKWARD from the
+        same start (which re-adds the start row when the forward fill stopped short) - CFFM.py:560-581."""
+        start_index = np.random.randint(0, len(data['Y']) - batch_size)
+        want = len(data['X'][start_index])
+        X, Y = [], []
+        for step in (1, -1):
+            i = start_index
+            while len(X) < batch_size and 0 <= i < len(data['X']) and len(data['X'][i]) == want:
+                Y.append([data['Y'][i]])
+                X.append(data['X'][i])
+                i += step
+        return {'X': X, 'Y': Y}
+
+    def get_ordered_block_from_data(self, data, batch_size, index):
+        start_index = index * batch_size
+        X, Y = [], []
+        i = start_index
+        while len(X) < batch_size and i < len(data['X']) and len(data['X'][i]) == len(data['X'][start_index]):
+            Y.append(data['Y'][i])
+            X.append(data['X'][i])
+            i += 1
+        return {'X': X, 'Y': Y}
+
+    def eva_termination(self, valid):
+        if len(valid) > 5:
+            if valid[-1] > valid[-2] > valid[-3] > valid[-4] > valid[-5]:
+                return True
+        return False
+
+    def calculate_parameters(self):
+        total_parameters = logged_param_count(self.config)
+        if self.verbose > 0:
+            logging.info("#params: %d" % total_parameters)
+        return total_parameters
+
+    def create_save_folder(self, save_file):
+        if not os.path.exists(save_file):
+            os.makedirs(save_file)
+
+    # ---- checkpoint: this model's tensors AND the Adagrad accumulators (the reference restore is broken, Q7) ---
+    def save(self, save_file):
+        import torch
+        torch.save({'config': self.config.__dict__, 'params': self.engine.export_params(),
+                    'accumulators': self.engine.export_accumulators()}, save_file + '.pt')
+
+    def load(self, save_file):
+        import torch
+        blob = torch.load(save_file + '.pt', weights_only=False)
+        self.engine.load_params(blob['params'], blob['accumulators'])
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    configure_logging('logging.log')
+    if args.verbose > 0:
+        logging.info(
+            "CFFM: dataset=%s, factors=%d, loss_type=%s, #epoch=%d, batch=%d, lr=%.4f, lambda=%.1e, keep=%s, optimizer=%s"
+            ", batch_norm=%d, num_field=%d, linear_att=%d, att_dim=%d,lamda_att=%.2f,inner_conv=%d,gamma_inner=%.1f,"
+            "outer_conv=%d,beta_outer=%.1f, activation=%s"
+            % (args.dataset, args.inner_dims, args.loss_type, args.epoch, args.batch_size, args.lr, args.lamda,
+               eval(args.keep), args.optimizer, args.batch_norm, args.num_field, args.linear_att, args.att_dim,
+               args.lamda_att, args.inner_conv, args.gamma_inner, args.outer_conv, args.beta_outer, args.activation))
+    data = DATA.LoadData(args.path, args.dataset, args.loss_type)
+    save_file = 'pretrain/CFFM/%s_%d/%s_%d' % (args.dataset, args.inner_dims, args.dataset, args.inner_dims)
+    t1 = time()
+    cf_fm = CFFM(data.features_M, args.pretrain, save_file, args.inner_dims, args.outer_dims, args.loss_type,
+                 args.epoch, args.batch_size, args.lr, args.lamda, eval(args.keep), args.optimizer, args.batch_norm,
+                 args.verbose, args.tensorboard, args.num_field, args.linear_att, args.att_dim, args.lamda_att,
+                 args.inner_conv, args.gamma_inner, args.outer_conv, args.beta_outer, args.activation)
+    cf_fm.train(data)
+    best_valid_score = min(cf_fm.valid_rmse)
+    best_epoch = cf_fm.valid_rmse.index(best_valid_score)
+    logging.info("Best Iter of RMSE (validation)= %d train = %.4f, valid = %.4f, test = %.4f [%.1f s]"
+                 % (best_epoch + 1, cf_fm.train_rmse[best_epoch], cf_fm.valid_rmse[best_epoch],
+                    cf_fm.test_rmse[best_epoch], time() - t1))
+    best_r2 = cf_fm.valid_r2.index(max(cf_fm.valid_r2))
+    logging.info("Best Iter of R2 (validation)= %d train = %.4f, valid = %.4f, test = %.4f [%.1f s]"
+                 % (best_epoch + 1, cf_fm.train_r2[best_r2], cf_fm.valid_r2[best_r2], cf_fm.test_r2[best_r2],
+                    time() - t1))       # prints best_epoch + 1 from the RMSE search, as the reference does (Q15)
+    return cf_fm
+
+
+if __name__ == '__main__':
+    main()

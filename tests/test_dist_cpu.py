@@ -1,0 +1,184 @@
+"""N > 1 path on CPU: world_size-2 gloo runs of cffm_amd.dist.  The collectives, routing and dedup logic are
+the product's; the per-rank compute is stood in by the float64 oracle (test infrastructure), so the check
+is exact: a 2-rank data-parallel step on two half batches == one oracle step on the whole batch."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cffm_amd.spec import CFFMConfig, init_params  # noqa: E402
+from oracle import cffm_oracle as orc  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == 'ok', r[2]
+    return {r[0]: r[2] for r in res}
+
+
+def _entry(fn, rank, world, port, q, *args):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(1)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        out = fn(rank, world, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok', out))
+    except Exception:
+        q.put((rank, 'fail', traceback.format_exc()))
+
+
+class OracleCompute(object):
+    """HipEngine's step-half interface on CPU tensors, computed by the float64 oracle."""
+
+    def __init__(self, cfg, p):
+        self.cfg, self.p = cfg, p
+        self.acc = orc.init_accumulators(p)
+        self.names = [k for k in orc.DENSE_TRAINED] + \
+                     ['outer_layer_conv_%s_%d' % (w, l) for l in range(cfg.Lc - 1) for w in ('weight', 'bias')]
+        self.sizes = [int(np.prod(p[k].shape)) if p[k].shape else 1 for k in self.names]
+        self.grad = torch.zeros(sum(self.sizes), dtype=torch.float64)
+        self.sc = torch.zeros(16, dtype=torch.float64)
+
+    def forward(self, ids, y):
+        self.X = ids.numpy()
+        self.out, self.cache = orc.forward(self.p, self.X, self.cfg)
+        self.sc[0] = float(np.sum((y.numpy() - self.out) ** 2))
+
+    def loss_sum_local(self, B):
+        return self.sc[0:1]
+
+    def set_loss_sum_global(self, B, s):
+        self.sc[3:4] = s
+
+    def loss_value(self, B):
+        return self.sc[1:2]
+
+    def backward(self, y, B, Bg):
+        L = np.sqrt(float(self.sc[3]) / Bg + 1e-10)
+        self.sc[1] = L
+        dout = (self.out - y.numpy()) / (Bg * L)
+        self.g = orc.backward(self.p, self.cache, dout, self.cfg)
+        self.grad[:] = torch.from_numpy(np.concatenate([np.asarray(self.g[k]).reshape(-1) for k in self.names]))
+
+    def row_grads(self, B):
+        return tuple(torch.from_numpy(np.ascontiguousarray(self.g[k])) for k in ('d_inner_rows', 'd_outer_rows', 'd_bias_rows'))
+
+    def apply_dense(self):
+        flat, o = self.grad.numpy(), 0
+        for k, n in zip(self.names, self.sizes):
+            gk = flat[o:o + n].reshape(self.p[k].shape)
+            o += n
+            if self.p[k].shape == ():
+                a = self.acc[k] + gk * gk
+                self.acc[k] = a
+                self.p[k] = self.p[k] - self.cfg.lr * gk / np.sqrt(a)
+            else:
+                orc.adagrad_dense(self.p[k], self.acc[k], gk, self.cfg.lr)
+
+    def apply_sparse(self, ids, dEi, dEo, dfb, B_ws):
+        i = ids.numpy()
+        orc.adagrad_sparse(self.p['inner_embeddings'], self.acc['inner_embeddings'], i, dEi.numpy(), self.cfg.lr)
+        orc.adagrad_sparse(self.p['outer_embeddings'], self.acc['outer_embeddings'], i, dEo.numpy(), self.cfg.lr)
+        orc.adagrad_sparse(self.p['feature_bias'], self.acc['feature_bias'], i, dfb.numpy().reshape(-1, 1), self.cfg.lr)
+
+
+def _case():
+    cfg = CFFMConfig(M=50, F=4, K=8, D=8, activation='selu', lamda_att=1.5)
+    p = init_params(cfg, seed=3, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    p['feature_bias'] = rng.standard_normal(p['feature_bias'].shape) * 0.3
+    p['outer_embeddings'] *= 20
+    X = rng.integers(0, cfg.M, size=(8, cfg.F))
+    X[5] = X[0]                                  # the same ids on both ranks: cross-rank duplicates
+    y = rng.choice([-1.0, 1.0], size=8)
+    return cfg, p, X, y
+
+
+def _dp_worker(rank, world):
+    from cffm_amd.dist import DataParallelStep
+    cfg, p, X, y = _case()
+    comp = OracleCompute(cfg, p)
+    step = DataParallelStep(comp)
+    sl = slice(rank * 4, rank * 4 + 4)
+    loss = step.train_step(torch.from_numpy(X[sl]), torch.from_numpy(y[sl]))
+    return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}
+
+
+def test_data_parallel_step_equals_single_process_step():
+    res = _run(_dp_worker, 2)
+    cfg, p, X, y = _case()
+    acc = orc.init_accumulators(p)
+    L, _ = orc.train_step(p, acc, X, y, cfg)
+    for rank in (0, 1):
+        loss, got = res[rank]
+        assert abs(loss - L) < 1e-12
+        for k, v in got.items():
+            np.testing.assert_allclose(v, p[k], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
+    for k in res[0][1]:                           # replicas stay bit-identical
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+
+
+def _shard_worker(rank, world):
+    from cffm_amd.dist import ShardedTables
+    M, dim = 37, 5
+    full = torch.arange(M * dim, dtype=torch.float64).reshape(M, dim)
+    bias = torch.arange(M, dtype=torch.float64).reshape(M, 1) * 0.5
+    local = {'emb': full[rank::world].clone(), 'bias': bias[rank::world].clone()}
+    st = ShardedTables(local)
+    rng = np.random.default_rng(100 + rank)
+    ids = torch.from_numpy(rng.integers(0, M, size=23))
+    rows = st.lookup(ids)
+    assert torch.equal(rows['emb'], full[ids]) and torch.equal(rows['bias'], bias[ids])
+    grads = {'emb': torch.from_numpy(rng.standard_normal((23, dim))), 'bias': torch.from_numpy(rng.standard_normal((23, 1)))}
+    local_rows, recv = st.push_grads(grads)
+    dense = torch.zeros(M, dim, dtype=torch.float64)
+    dense.index_add_(0, ids, grads['emb'])
+    owned = torch.zeros_like(local['emb'])
+    owned.index_add_(0, local_rows, recv['emb'])
+    return dense.numpy(), owned.numpy()
+
+
+def test_row_sharded_lookup_and_gradient_routing():
+    res = _run(_shard_worker, 2)
+    total = res[0][0] + res[1][0]                 # what an unsharded table would accumulate over both ranks
+    for rank in (0, 1):
+        np.testing.assert_allclose(res[rank][1], total[rank::2], rtol=1e-12, atol=1e-12)
+
+
+def test_route_ids_is_a_stable_grouping():
+    from cffm_amd.dist import route_ids, shard_of
+    ids = torch.tensor([7, 2, 9, 4, 4, 1, 8])
+    perm, counts = route_ids(ids, 3)
+    owner = ids[perm] % 3
+    assert counts.tolist() == [1, 4, 2] and torch.equal(owner, torch.sort(owner)[0])
+    assert ids[perm].tolist() == [9, 7, 4, 4, 1, 2, 8]       # stable inside each owner group
+    o, l = shard_of(ids, 3)
+    assert torch.equal(o * 1 + l * 3, ids)
