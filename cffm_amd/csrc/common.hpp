@@ -128,6 +128,10 @@ __device__ __forceinline__ void build_pair_lut(uint32_t* lut, int F, int Pp) {
     for (int p = P + threadIdx.x; p < Pp; p += blockDim.x) lut[p] = 0u;   // padded pairs -> (0,0), weights are 0
 }
 
+// n / d for 0 <= n < 2^19 and 1 <= d <= 2048 without the ~40-instruction integer division sequence:
+// (n + 0.5) * (1/d) is at least 0.5/d away from every integer, far above the fp32 rounding error.
+__device__ __forceinline__ int fast_div(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

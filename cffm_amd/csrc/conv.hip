@@ -22,6 +22,7 @@
 #include "common.hpp"
 
 #define KSTEP 32
+#define WG_KM 64       // rows of the M (reduction) dimension staged per wgrad step
 
 struct RowPos { int b, y, x; };
 __device__ __forceinline__ RowPos row_pos(int64_t m, int lgSo) {
@@ -101,10 +102,11 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, flo
 __device__ __forceinline__ void stage_examples(float* Es, const float* __restrict__ Eo, int b0, int n_ex, int B,
                                                int F, int D, int Dp) {
     const int per = F * D;
+    const float invD = 1.f / (float)D;
     for (int e = threadIdx.x; e < n_ex * per; e += blockDim.x) {
-        const int ex = e / per, rem = e - ex * per, f = rem / D, d = rem - f * D;
-        const int b = b0 + ex;
-        Es[(ex * F + f) * Dp + d] = b < B ? Eo[(int64_t)b * per + rem] : 0.f;
+        const int row = fast_div(e, invD), d = e - row * D;          // row = ex * F + f
+        const int64_t src = (int64_t)b0 * per + e;
+        Es[row * Dp + d] = src < (int64_t)B * per ? Eo[src] : 0.f;
     }
 }
 
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     float* Es = reinterpret_cast<float*>(lut + a.Pp);             // [n_ex][F][Dp] (GEN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1;
+    const float invPp = 1.f / (float)Pp;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int nvalid = min(NT, (Pp - n0) / 16);
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = ks * KSTEP + 16 * h;
-            const int tap = k / Pp, pb = k - tap * Pp, dh = tap >> 1, dw = tap & 1;
+            const int tap = fast_div(k, invPp), pb = k - tap * Pp, dh = tap >> 1, dw = tap & 1;
             if (GEN) {
                 const uint4 l4 = *reinterpret_cast<const uint4*>(&lut[pb + 4 * kk]);
                 const uint32_t ij[4] = {l4.x, l4.y, l4.z, l4.w};
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int e = tid + 256 * i, kr = e / BN, c = e % BN;
-            const int k = ks * KSTEP + kr, tap = k / Pp, p = k - tap * Pp, n = n0 + c;
+            const int k = ks * KSTEP + kr, tap = fast_div(k, invPp), p = k - tap * Pp, n = n0 + c;
             wreg[i] = (p < P && n < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + n] : 0.f;
         }
     };
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
     float* Es = reinterpret_cast<float*>(lut + a.Pp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
+    const float invPp = 1.f / (float)Pp;
     const int Ntot = 4 * Pp;
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
     const int exsz = a.F * Dp;
     float* dEw = Es + n_ex * exsz + wave * (n_ex * exsz);     // this wave's private accumulators
     float* rs = Es + 5 * n_ex * exsz;                          // [n_ex][F] row sums, then [n_ex][F] dots
+    const bool fast = L0 && a.lgSo >= 4;   // a 16-row tile is 16 consecutive x of ONE (b, y)
     if (L0) {
         build_pair_lut(lut, a.F, Pp);
         stage_examples(Es, a.Cprev, b0, n_ex, a.B, a.F, a.D, Dp);
@@ -255,18 +260,27 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
         __syncthreads();
     }
 
-    for (int mt = 0; mt < mtiles; ++mt) {
-        const int64_t m0 = wg_m0 + (int64_t)mt * BM;
-        int64_t arow[RM];
+    for (int nb = 0; nb < nblocks; ++nb) {
+        const int n0 = (L0 ? nb : blockIdx.y) * BN;
+        const int nvalid = min(NT, (Ntot - n0) / 16);
+        // fast path, j-side: dEo[j_p][2x+dw] sums over y and dh -> keep it in registers across the m tiles
+        float accj[RM][NT][4];
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm) {
-            int64_t m = m0 + wave * (16 * RM) + rm * 16 + r;
-            if (m >= a.Mtot) m = a.Mtot - 1;
-            arow[rm] = m * Pp + 4 * kk;
-        }
-        for (int nb = 0; nb < nblocks; ++nb) {
-            const int n0 = (L0 ? nb : blockIdx.y) * BN;
-            const int nvalid = min(NT, (Ntot - n0) / 16);
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accj[rm][nt][j] = 0.f;
+
+        for (int mt = 0; mt < mtiles; ++mt) {
+            const int64_t m0 = wg_m0 + (int64_t)mt * BM;
+            int64_t arow[RM];
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) {
+                int64_t m = m0 + wave * (16 * RM) + rm * 16 + r;
+                if (m >= a.Mtot) m = a.Mtot - 1;
+                arow[rm] = m * Pp + 4 * kk;
+            }
             auto loadA = [&](int ks, float4 (&reg)[RM][2]) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2 * NT; ++i) {
                     const int e = tid + 256 * i, c = e / KSTEP, kr = e % KSTEP;
-                    const int q = ks * KSTEP + kr, n = n0 + c, tap = n / Pp, p = n - tap * Pp;
+                    const int q = ks * KSTEP + kr, n = n0 + c, tap = fast_div(n, invPp), p = n - tap * Pp;
                     wreg[i] = (q < P && p < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + q] : 0.f;
                 }
             };
@@ -295,14 +309,16 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
             // ---- epilogue ------------------------------------------------------------------------
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) {
+                const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
+                const RowPos rq = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);   // fast path: (b, y) of the tile
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if (nt >= nvalid) continue;
-                    const int n = n0 + nt * 16 + r, tap = n / Pp, p = n - tap * Pp, dh = tap >> 1, dw = tap & 1;
+                    const int n = n0 + nt * 16 + r, tap = fast_div(n, invPp), p = n - tap * Pp, dh = tap >> 1, dw = tap & 1;
                     if (!L0) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                            const int64_t m = mrow + j;
                             if (m < a.Mtot) {
                                 const RowPos rp = row_pos(m, a.lgSo);
                                 const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * Pp + p;
@@ -314,28 +330,23 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
                         const uint32_t ij = lut[p];
                         const int fi = ij & 0xffff, fj = ij >> 16;
                         const bool pv = p < P;
-                        if (a.lgSo >= 4) {
-                            // the 16 rows of this tile share (b, y): reduce the i-side over x in registers
-                            const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
-                            const RowPos rp = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);
-                            const int eb = (rp.b - b0) * exsz;
-                            const float ei = Es[eb + fi * Dp + 2 * rp.y + dh];
+                        if (fast) {
+                            const int eb = (rq.b - b0) * exsz;
+                            const float ei = Es[eb + fi * Dp + 2 * rq.y + dh];
                             float si = 0.f;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const bool ok = pv && (mrow + j < a.Mtot);
-                                const float v = ok ? acc[rm][nt][j] : 0.f;
-                                const int xo = 2 * (rp.x + j) + dw;
-                                si += v * Es[eb + fj * Dp + xo];
-                                if (ok) atomicAdd(&dEw[eb + fj * Dp + xo], v * ei);
+                                const float v = (pv && mrow + j < a.Mtot) ? acc[rm][nt][j] : 0.f;
+                                si += v * Es[eb + fj * Dp + 2 * (rq.x + j) + dw];
+                                accj[rm][nt][j] += v * ei;
                             }
                             si += __shfl_xor(si, 16, 64);
                             si += __shfl_xor(si, 32, 64);
-                            if (kk == 0 && pv) atomicAdd(&dEw[eb + fi * Dp + 2 * rp.y + dh], si);
+                            if (kk == 0 && pv) atomicAdd(&dEw[eb + fi * Dp + 2 * rq.y + dh], si);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                                const int64_t m = mrow + j;
                                 if (pv && m < a.Mtot) {
                                     const RowPos rp = row_pos(m, a.lgSo);
                                     const int eb = (rp.b - b0) * exsz;
@@ -350,6 +361,25 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
                 }
             }
         }
+        if (fast) {
+            // flush the j-side: in the fast path S2 >= 256 >= BM, so the workgroup holds ONE example and the
+            // x of (rm, kk, j) does not depend on the m tile
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) {
+                const int64_t mrow = wg_m0 + wave * (16 * RM) + rm * 16 + kk * 4;
+                const RowPos rq = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt >= nvalid) continue;
+                    const int n = n0 + nt * 16 + r, tap = fast_div(n, invPp), p = n - tap * Pp, dw = tap & 1;
+                    if (p < P) {
+                        const int fj = lut[p] >> 16;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&dEw[fj * Dp + 2 * (rq.x + j) + dw], accj[rm][nt][j]);
+                    }
+                }
+            }
+        }
     }
     if (L0) {
         // merge the four private copies in wave order and add the closed-form sum-pool (s0) terms:
@@ -358,11 +388,11 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
         float* acc0 = Es + n_ex * exsz;
         float* dots = rs + n_ex * a.F;
         for (int e = tid; e < n_ex * a.F; e += 256) {
-            const int ex = e / a.F, f = e - ex * a.F, b = b0 + ex;
+            const int b = b0 + e / a.F;
             float s = 0.f, d = 0.f;
             if (b < a.B)
                 for (int h = 0; h < a.D; ++h) {
-                    const float v = Es[(ex * a.F + f) * Dp + h];
+                    const float v = Es[e * Dp + h];
                     s += v;
                     d += v * a.dt1[(int64_t)b * a.t1w + h];
                 }
@@ -370,15 +400,16 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
         }
         __syncthreads();
         const int per = a.F * a.D;
+        const float invD = 1.f / (float)a.D, invF = 1.f / (float)a.F;
         for (int e = tid; e < n_ex * per; e += 256) {
-            const int ex = e / per, rem = e - ex * per, f = rem / a.D, h = rem - f * a.D, b = b0 + ex;
+            const int row = fast_div(e, invD), h = e - row * a.D, ex = fast_div(row, invF), f = row - ex * a.F, b = b0 + ex;
             if (b >= a.B) continue;
             float R = 0.f, Q = 0.f;
             for (int j = f + 1; j < a.F; ++j) R += rs[ex * a.F + j];
             for (int i = 0; i < f; ++i) Q += dots[ex * a.F + i];
-            const int o = (ex * a.F + f) * Dp + h, st = n_ex * exsz;
+            const int o = row * Dp + h, st = n_ex * exsz;
             const float conv = ((acc0[o] + acc0[st + o]) + acc0[2 * st + o]) + acc0[3 * st + o];
-            a.dprev[(int64_t)b * per + rem] = conv + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+            a.dprev[(int64_t)b0 * per + e] = conv + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
         }
     }
 }
@@ -398,7 +429,8 @@ struct WgradArgs {
 
 template <int NT, bool GEN>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    constexpr int BI = 64, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = 32;
+    constexpr int BI = 64, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = WG_KM;
+    constexpr int NB = KM * BQ / 256, NA = KM * BI / 4 / 256;     // per-thread B' floats / A' float4s per step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);                       // [KM][LDB]
     float* As = Bs + KM * LDB;                                        // [KM][LDA]      (!GEN)
@@ -406,6 +438,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     float* Es = reinterpret_cast<float*>(lut + (GEN ? a.Pp : 0));     // [n_ex][F][Dp] (GEN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
+    const float invPp = 1.f / (float)Pp;
     const int ib = blockIdx.x / a.qblocks, qb = blockIdx.x - ib * a.qblocks;
     const int i0 = ib * BI, q0 = qb * BQ;
     const int nvalid = min(NT, (Pp - q0) / 16);
@@ -417,7 +450,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
     // the (tap, p) this lane's A' row belongs to
     const int irow = i0 + wave * 16 + r;
-    const int tapA = irow / Pp, pA = irow - tapA * Pp, dhA = tapA >> 1, dwA = tapA & 1;
+    const int tapA = fast_div(irow, invPp), pA = irow - tapA * Pp, dhA = tapA >> 1, dwA = tapA & 1;
     int fi = 0, fj = 0;
     if (GEN) {
         build_pair_lut(lut, a.F, Pp);
@@ -425,51 +458,62 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const uint32_t ij = lut[pA];
         fi = ij & 0xffff; fj = ij >> 16;
     }
+    // staging geometry of this thread (fixed over the steps)
+    int a_tap[NA], a_p[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int ii = i0 + 4 * ((tid + 256 * i) % 16);
+        a_tap[i] = fast_div(ii, invPp);
+        a_p[i] = ii - a_tap[i] * Pp;
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     int cur_b = -1;
+    float breg[NB];
+    float4 areg[NA > 0 ? NA : 1];
 
-    for (int64_t st = s_lo; st < s_hi; ++st) {
+    auto fetch = [&](int64_t st) {            // global -> registers for step st
         const int64_t mbase = st * KM;
-        // ---- global -> registers ----------------------------------------------------------------
-        float breg[2 * NT];
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int e = tid + 256 * i, row = e / BQ, c = e % BQ;
             const int64_t m = mbase + row;
             breg[i] = (m < a.Mtot && q0 + c < Pp) ? a.dC[m * Pp + q0 + c] : 0.f;
         }
-        float4 areg[2];
         if (!GEN) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int u = tid + 256 * i, row = u / 16, c4 = u % 16;
-                const int64_t m = mbase + row;
-                const int ii = i0 + 4 * c4, tap = ii / Pp, p = ii - tap * Pp;
+            for (int i = 0; i < NA; ++i) {
+                const int64_t m = mbase + (tid + 256 * i) / 16;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < a.Mtot) {
                     const RowPos rp = row_pos(m, a.lgSo);
-                    const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + (tap >> 1)) * Sin + 2 * rp.x + (tap & 1)) * Pp + p;
+                    const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + (a_tap[i] >> 1)) * Sin + 2 * rp.x + (a_tap[i] & 1)) * Pp + a_p[i];
                     v = *reinterpret_cast<const float4*>(a.in + pos);
-                    v.x = act_pos(v.x, a.act); v.y = act_pos(v.y, a.act);
-                    v.z = act_pos(v.z, a.act); v.w = act_pos(v.w, a.act);
                 }
                 areg[i] = v;
             }
         }
+    };
+
+    if (s_lo < s_hi) fetch(s_lo);
+    for (int64_t st = s_lo; st < s_hi; ++st) {
+        const int64_t mbase = st * KM;
         __syncthreads();                                   // previous step's LDS reads are done
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int e = tid + 256 * i;
             Bs[(e / BQ) * LDB + (e % BQ)] = breg[i];
         }
         if (!GEN) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int u = tid + 256 * i;
-                *reinterpret_cast<float4*>(&As[(u / 16) * LDA + 4 * (u % 16)]) = areg[i];
+                float4 v = areg[i];
+                v.x = act_pos(v.x, a.act); v.y = act_pos(v.y, a.act);
+                v.z = act_pos(v.z, a.act); v.w = act_pos(v.w, a.act);
+                *reinterpret_cast<float4*>(&As[(u / 16) * LDA + 4 * (u % 16)]) = v;
             }
         } else {
             const int bl = (int)(mbase >> (2 * a.lgSo));
@@ -479,8 +523,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         }
         __syncthreads();
-        // ---- MFMA over the 32 rows ------------------------------------------------------------------
-#pragma unroll
+        if (st + 1 < s_hi) fetch(st + 1);                 // in flight while this step's MFMAs run
+        // ---- MFMA over the KM rows ------------------------------------------------------------------
+#pragma unroll 4
         for (int ks4 = 0; ks4 < KM; ks4 += 4) {
             float av;
             if (GEN) {
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int q = q0 + nt * 16 + r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = i0 + wave * 16 + kk * 4 + j, tap = i / Pp, p = i - tap * Pp;
+            const int i = i0 + wave * 16 + kk * 4 + j, tap = fast_div(i, invPp), p = i - tap * Pp;
             if (p < P && q < P && tap < 4) sw[(int64_t)(tap * P + p) * P + q] = acc[nt][j];
         }
     }
@@ -582,8 +627,8 @@ template <int NT, bool GEN>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     constexpr int BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
     const int S2 = 1 << (2 * a.lgSo);
-    const int n_ex = GEN ? (32 > S2 ? 32 / S2 : 1) : 0;
-    const size_t lds = (size_t)(32 * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 32 * 80) + 4) * 4;
+    const int n_ex = GEN ? (WG_KM > S2 ? WG_KM / S2 : 1) : 0;
+    const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * 80) + 4) * 4;
     int rc = set_lds(wgrad_kernel<NT, GEN>, lds);
     if (rc) return rc;
     dim3 grid((unsigned)((4 * a.Pp / 64) * a.qblocks), CFFM_NSLAB);

@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void inner_fwd_kernel(Geo g, const float* __re
     float cb[2] = {cb_g[0], cb_g[1]};
     __syncthreads();
     const int K2 = g.K / 2, units = g.P * K2;
+    const float invK2 = 1.f / (float)K2;
     float part = 0.f;
     for (int u = threadIdx.x; u < units; u += blockDim.x) {
-        const int p = u / K2, t = u - p * K2;
+        const int p = fast_div(u, invK2), t = u - p * K2;
         const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, g.act);
         const float2 w2 = *reinterpret_cast<const float2*>(&wd[(int64_t)p * g.K + 2 * t]);   // flat index p*K + t*2 + ch (:333)
         part += v.s0 * w2.x + v.s1 * w2.y;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void inner_bwd_kernel(Geo g, int B, const floa
     float cw[4] = {cw_g[0], cw_g[1], cw_g[2], cw_g[3]};
     float cb[2] = {cb_g[0], cb_g[1]};
     const int K2 = g.K / 2, units = g.P * K2;
+    const float invK2 = 1.f / (float)K2;
     float gcw[4] = {0.f, 0.f, 0.f, 0.f}, gcb[2] = {0.f, 0.f}, gdb = 0.f;
     bool first = true;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void inner_bwd_kernel(Geo g, int B, const floa
         const float db = dout[b];
         float* myE = dE + wave * FK;
         for (int u = threadIdx.x; u < units; u += blockDim.x) {
-            const int p = u / K2, t = u - p * K2;
+            const int p = fast_div(u, invK2), t = u - p * K2;
             const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, g.act);
             const int64_t wi = (int64_t)p * g.K + 2 * t;
             const float2 w2 = *reinterpret_cast<const float2*>(&wd[wi]);

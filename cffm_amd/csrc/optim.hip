@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];
+#pragma unroll 16
+    for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];     // independent loads, fixed add order
     grad[i] = s;
 }
 

@@ -87,7 +87,7 @@ def test_train_and_evaluate_end_to_end(tmp_path, caplog):
     import logging
     with contextlib.redirect_stdout(io.StringIO()):
         data = LoadData(PATH, 'frappe', 'square_loss')
-    m = make(tmp_path, epoch=6, batch_size=16, pretrain_flag=-1)
+    m = make(tmp_path, epoch=40, batch_size=16, pretrain_flag=-1)   # the oracle needs ~10 epochs on this slice too
     with caplog.at_level(logging.INFO):
         m.train(data)
     assert len(m.train_rmse) == len(m.valid_rmse) == len(m.test_rmse) >= 1
@@ -99,7 +99,9 @@ def test_train_and_evaluate_end_to_end(tmp_path, caplog):
     assert '#params: %d' % m.calculate_parameters() in text and 'Init_RMSE: train=' in text and 'Epoch 1 [' in text
     rmse, r2 = m.evaluate(data.Validation_data)
     assert rmse == pytest.approx(m.valid_rmse[-1], rel=1e-6)
-    # checkpoint round trip (--pretrain -1 saved every epoch): a fresh model restored from it predicts the same
+    # checkpoint round trip (--pretrain -1 / 1): a fresh model restored from the file predicts the same
+    assert os.path.exists(m.save_file + '.pt')                # written every epoch by --pretrain -1
+    m.save(m.save_file)
     m2 = make(tmp_path, pretrain_flag=1)
     m2.build_graph()
     r2mse, _ = m2.evaluate(data.Validation_data)
