@@ -111,7 +111,7 @@ def stage_times(eng, ids, y):
         stages.append(('conv%d_bwd' % l, lambda l=l: lib.cffm_conv_bwd(sref, P(eng.theta), P(buf), B, l, st())))
     stages.append(('conv0_bwd', lambda: lib.cffm_outer_conv0_bwd(sref, P(eng.theta), P(buf), B, st())))
     stages.append(('inner_bwd', lambda: lib.cffm_inner_bwd(sref, P(eng.theta), P(buf), B, st())))
-    stages.append(('reduce_slabs', lambda: lib.cffm_reduce_slabs(sref, P(buf), P(eng.grad), st())))
+    stages.append(('reduce_slabs', lambda: lib.cffm_reduce_slabs(sref, P(buf), B, P(eng.grad), st())))
     out = {}
     for name, fn in stages:              # in step order, so every stage sees valid inputs
         out[name] = round(event_time_ms(lambda: hip.check(fn()), 20) * 1e3, 2)

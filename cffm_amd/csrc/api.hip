@@ -1,6 +1,6 @@
 // Layout queries and the composite entry points (what CFFM.evaluate / CFFM.train call in place of the
 // two sess.run()s, CFFM.py:200 and :596).
-#include "common.hpp"
+#include "internal.hpp"
 
 #include <string.h>
 
@@ -30,8 +30,8 @@ extern "C" int cffm_theta_layout(const cffm_shape_t* s, cffm_theta_layout_t* out
     out->inner_dw = take((int64_t)g.P * g.K);
     out->inner_db = take(1);
     for (int l = 0; l < g.live; ++l) {
-        out->conv_w[l] = take((int64_t)4 * g.P * g.P);
-        out->conv_b[l] = take(g.P);
+        out->conv_w[l] = take((int64_t)4 * g.Pp * g.Pp);     // [tap][Pp][Pp], zero outside [P][P]
+        out->conv_b[l] = take(g.Pp);
     }
     out->d1_w = take((int64_t)(2 * g.D - 2) * CFFM_HEAD_UNITS);
     out->d1_b = take(CFFM_HEAD_UNITS);
@@ -80,16 +80,24 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     out->dEo = take(b * g.F * g.D * 4);
     out->dfb = take(b * g.F * 4);
     const int64_t nrows = b * g.F;
-    out->sort_keys = take(nrows * 4);
-    out->sort_vals = take(nrows * 4);
-    out->sort_tmp_bytes = (nrows * 4 + 255) / 256 * 256 + nrows * 16 + (4 << 20);
+    out->sort_keys = take(nrows * 8);                            // packed (id << 32 | slot), unsorted
+    out->sort_vals = take(nrows * 8);                            // the same keys, sorted
+    out->sort_tmp_bytes = nrows * 32 + (4 << 20);
     out->sort_tmp = take(out->sort_tmp_bytes);
+    // big conv layers get a finer split of their weight gradient than CFFM_NSLAB (tap-split path only)
+    for (int l = 0; l < g.live; ++l) {
+        const int64_t S = g.D >> (l + 1);
+        if (s->outer_conv && g.Pp <= 64 && b * S * S >= 256 * 64) {
+            out->xslabs[l] = 256;
+            out->xpart[l] = take((int64_t)256 * (4 * g.Pp * g.Pp + g.Pp) * 4);
+        }
+    }
     out->bytes = o;
     return 0;
 }
 
-extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
-                            const float* y, int32_t B, void* ws, void* stream) {
+static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                        const float* y, int32_t B, void* ws, bool fused_step, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -97,8 +105,9 @@ extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, con
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
     const Geo g = make_geo(s);
-    rc = cffm_gather(s, tab, ids, B, s->inner_conv ? (float*)(w + wl.Ei) : nullptr,
-                     s->outer_conv ? (float*)(w + wl.Eo) : nullptr, (float*)(w + wl.fb), stream);
+    rc = cffm_gather_impl(s, tab, ids, B, s->inner_conv ? (float*)(w + wl.Ei) : nullptr,
+                          s->outer_conv ? (float*)(w + wl.Eo) : nullptr, (float*)(w + wl.fb),
+                          fused_step ? (unsigned long long*)(w + wl.sort_keys) : nullptr, stream);
     if (rc) return rc;
     if ((rc = cffm_inner_fwd(s, theta, ws, B, stream))) return rc;
     if (s->outer_conv) {
@@ -106,7 +115,12 @@ extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, con
         for (int l = 1; l < g.live; ++l)
             if ((rc = cffm_conv_fwd(s, theta, ws, B, l, stream))) return rc;
     }
-    return cffm_head_fwd(s, theta, ws, y, B, stream);
+    return cffm_head_fwd_impl(s, theta, ws, y, B, !fused_step, stream);
+}
+
+extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                            const float* y, int32_t B, void* ws, void* stream) {
+    return forward_impl(s, tab, theta, ids, y, B, ws, false, (hipStream_t)stream);
 }
 
 extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
@@ -122,8 +136,9 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
     return 0;
 }
 
-extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const float* y, int32_t B, int64_t B_global,
-                             void* ws, float* grad, void* stream) {
+// backward through the slab reduction; fused = single-GPU step (local loss sum, Adagrad folded into the reduction)
+static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
+                         int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -132,37 +147,37 @@ extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const fl
     const Geo g = make_geo(s);
     char* w = (char*)ws;
     if (!s->inner_conv || !s->outer_conv || !s->linear_att) {   // slabs of a disabled branch must read as zeros
-        hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)CFFM_NSLAB * tl.n * 4, (hipStream_t)stream);
+        hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)CFFM_NSLAB * tl.n * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
-    if ((rc = cffm_head_bwd(s, theta, ws, y, B, B_global, stream))) return rc;
+    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused, loss_out, stream))) return rc;
     if (s->outer_conv) {
         for (int l = g.live - 1; l >= 1; --l)
             if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
         if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
     }
     if ((rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
-    return cffm_reduce_slabs(s, ws, grad, stream);
+    return cffm_reduce_slabs_impl(s, ws, B, grad, fused ? theta : nullptr, fused ? theta_acc : nullptr, s->lr, stream);
+}
+
+extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const float* y, int32_t B, int64_t B_global,
+                             void* ws, float* grad, void* stream) {
+    return backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr,
+                         (hipStream_t)stream);
 }
 
 extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,
                                float* theta, float* theta_acc, float* grad, const int32_t* ids, const float* y,
                                int32_t B, void* ws, float* loss, void* stream) {
-    int rc = cffm_forward(s, tab, theta, ids, y, B, ws, stream);    // leaves scalars[3] = local loss-term sum
+    hipStream_t st = (hipStream_t)stream;
+    int rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);
     if (rc || B <= 0) return rc;
-    if ((rc = cffm_backward(s, theta, y, B, (int64_t)B, ws, grad, stream))) return rc;
-    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
-    cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
+    if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
-    if ((rc = cffm_dense_adagrad(theta, theta_acc, grad, tl.n, s->lr, stream))) return rc;
-    rc = cffm_sparse_adagrad(s, tab, tab_acc, ids, (int64_t)B * s->F,
-                             s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
-                             s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb), ws, B,
-                             stream);
-    if (rc) return rc;
-    if (loss) {
-        hipError_t e = hipMemcpyAsync(loss, w + wl.scalars + 4, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
+    return cffm_sparse_adagrad_impl(s, tab, tab_acc, ids, (int64_t)B * s->F,
+                                    s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
+                                    s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),
+                                    ws, B, true, st);
 }

@@ -112,8 +112,8 @@ __device__ __forceinline__ void stage_examples(float* Es, const float* __restric
 
 struct ConvArgs {
     const float* in;     // GEN: Eo [B,F,D]; else C_{l-1} [B,Sin,Sin,Pp]
-    const float* W;      // HWIO [2,2,P,P] = [4P][P]
-    const float* bias;   // [P]
+    const float* W;      // [4][Pp][Pp] (HWIO padded)
+    const float* bias;   // [Pp]
     float* out;          // relu(conv + bias) [B,So,So,Pp]
     int64_t Mtot;        // B*So*So
     int B, lgSo, P, Pp, F, D, act;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int e = tid + 256 * i, kr = e / BN, c = e % BN;
-            const int k = ks * KSTEP + kr, tap = fast_div(k, invPp), p = k - tap * Pp, n = n0 + c;
-            wreg[i] = (p < P && n < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + n] : 0.f;
+            const int k = ks * KSTEP + kr, n = n0 + c;
+            wreg[i] = (k < 4 * Pp && n < Pp) ? a.W[k * Pp + n] : 0.f;
         }
     };
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             if (nt >= nvalid) continue;
             const int n = n0 + nt * 16 + r;
-            const float bv = n < P ? a.bias[n] : 0.f;
+            const float bv = a.bias[n];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2 * NT; ++i) {
                     const int e = tid + 256 * i, c = e / KSTEP, kr = e % KSTEP;
-                    const int q = ks * KSTEP + kr, n = n0 + c, tap = fast_div(n, invPp), p = n - tap * Pp;
-                    wreg[i] = (q < P && p < P && tap < 4) ? a.W[(int64_t)(tap * P + p) * P + q] : 0.f;
+                    const int q = ks * KSTEP + kr, n = n0 + c;
+                    wreg[i] = (q < Pp && n < Ntot) ? a.W[n * Pp + q] : 0.f;
                 }
             };
             f32x4 acc[RM][NT];
@@ -423,7 +423,7 @@ struct WgradArgs {
     const float* dC;     // [Mtot][Pp]
     float* slabW;        // slab 0 of conv_w[l]
     float* slabB;        // slab 0 of conv_b[l]
-    int64_t slab_stride, Mtot;
+    int64_t slab_stride, slabB_stride, Mtot;
     int B, lgSo, P, Pp, F, D, act, qblocks;
 };
 
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 if (m >= a.Mtot) m = a.Mtot - 1;             // B' rows beyond Mtot are zero
                 const RowPos rp = row_pos(m, a.lgSo);
                 const int eb = (rp.b - cur_b) * a.F * Dp;
-                av = Es[eb + fi * Dp + 2 * rp.y + dhA] * Es[eb + fj * Dp + 2 * rp.x + dwA];
+                av = pA < P ? Es[eb + fi * Dp + 2 * rp.y + dhA] * Es[eb + fj * Dp + 2 * rp.x + dwA] : 0.f;
             } else {
                 av = As[(ks4 + kk) * LDA + wave * 16 + r];
             }
@@ -554,11 +554,410 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int q = q0 + nt * 16 + r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = i0 + wave * 16 + kk * 4 + j, tap = fast_div(i, invPp), p = i - tap * Pp;
-            if (p < P && q < P && tap < 4) sw[(int64_t)(tap * P + p) * P + q] = acc[nt][j];
+            const int i = i0 + wave * 16 + kk * 4 + j;
+            sw[(int64_t)i * Pp + q] = acc[nt][j];
         }
     }
-    if (ib == 0 && tid < BQ && q0 + tid < P) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
+    if (ib == 0 && tid < BQ && q0 + tid < Pp) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
+}
+
+// =================================================================================================
+// Tap-split kernels for small channel counts (Pp = 16*NT <= 64, i.e. F <= 11: frappe, book-crossing, ml-tag).
+//
+// At these sizes a layer is a few hundred thousand MFMAs at most and a K loop with a barrier per step is
+// latency-bound.  Here the four wavefronts of a workgroup take one filter tap each, every load of a
+// wavefront is issued up front (one memory latency per workgroup instead of one per K step), and the only
+// barriers are the ones around the cross-tap reduction.
+//   conv_fwd_taps : wave t multiplies its 16*RM rows of tap t by W[t] (staged once into a wave-private LDS
+//                   quarter), the four partial tiles are summed through LDS in tap order.
+//   dgrad_taps    : wave t produces the gradient of tap t's input positions; the B fragments are rows of W
+//                   read straight from L2 as 16-byte pieces (no LDS, no barrier at all for L0 = false).
+// =================================================================================================
+template <int NT, int RM, bool GEN>
+__global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
+    constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
+    constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
+    float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int b0 = (int)(m0 >> (2 * a.lgSo));
+
+    // ---- issue every global load of this wave ----------------------------------------------------------
+    float4 wv[NW4];
+    const float4* wsrc = reinterpret_cast<const float4*>(a.W + tap * PP * PP);
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) wv[i] = wsrc[lane + 64 * i];
+    float4 av[RM][NT];
+    if (!GEN) {
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+            int64_t m = m0 + rm * 16 + r;
+            if (m >= a.Mtot) m = a.Mtot - 1;
+            const RowPos rp = row_pos(m, a.lgSo);
+            const float* src = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + 4 * kk;
+#pragma unroll
+            for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(src + 16 * h);
+        }
+    } else {
+        const int S2 = So * So;
+        const int n_ex = BM > S2 ? BM / S2 : 1;
+        build_pair_lut(lut, a.F, PP);
+        stage_examples(Es, a.in, b0, n_ex, a.B, a.F, a.D, Dp);
+    }
+    // ---- W[tap] -> this wave's LDS quarter ------------------------------------------------------------------
+    float* Wt = Wl + tap * (PP * LDW);
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+        const int u = lane + 64 * i, row = u / (PP / 4), c4 = u % (PP / 4);
+        *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[i];
+    }
+    __syncthreads();
+    if (GEN) {
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+            int64_t m = m0 + rm * 16 + r;
+            if (m >= a.Mtot) m = a.Mtot - 1;
+            const RowPos rp = row_pos(m, a.lgSo);
+            const int eoff = (rp.b - b0) * a.F * Dp;
+            const int iy = eoff + 2 * rp.y + dh, jx = eoff + 2 * rp.x + dw;
+#pragma unroll
+            for (int h = 0; h < NT; ++h) {
+                const uint4 l4 = *reinterpret_cast<const uint4*>(&lut[16 * h + 4 * kk]);
+                av[rm][h].x = Es[iy + (l4.x & 0xffff) * Dp] * Es[jx + (l4.x >> 16) * Dp];
+                av[rm][h].y = Es[iy + (l4.y & 0xffff) * Dp] * Es[jx + (l4.y >> 16) * Dp];
+                av[rm][h].z = Es[iy + (l4.z & 0xffff) * Dp] * Es[jx + (l4.z >> 16) * Dp];
+                av[rm][h].w = Es[iy + (l4.w & 0xffff) * Dp] * Es[jx + (l4.w >> 16) * Dp];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int h = 0; h < NT; ++h) {
+                av[rm][h].x = act_pos(av[rm][h].x, a.act); av[rm][h].y = act_pos(av[rm][h].y, a.act);
+                av[rm][h].z = act_pos(av[rm][h].z, a.act); av[rm][h].w = act_pos(av[rm][h].w, a.act);
+            }
+    }
+    // ---- MFMA: K = PP channels of this tap -----------------------------------------------------------------
+    f32x4 acc[RM][NT];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < NT; ++h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int krow = 16 * h + 4 * kk + t;
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = Wt[krow * LDW + nt * 16 + r];
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) {
+                const float x = t == 0 ? av[rm][h].x : t == 1 ? av[rm][h].y : t == 2 ? av[rm][h].z : av[rm][h].w;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = mfma16(x, bf[nt], acc[rm][nt]);
+            }
+        }
+    }
+    // ---- sum the four taps (fixed order) and write relu(conv + bias) ------------------------------------------
+    __syncthreads();                                           // every wave is done with its W quarter
+    f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RM*NT tiles][64 lanes]
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) red[(tap * RM * NT + rm * NT + nt) * 64 + lane] = acc[rm][nt];
+    __syncthreads();
+    for (int idx = tid; idx < RM * NT * 64; idx += 256) {
+        const int tile = idx >> 6, ln = idx & 63, rm = tile / NT, nt = tile - rm * NT;
+        f32x4 v = red[idx];
+        v += red[RM * NT * 64 + idx];
+        v += red[2 * RM * NT * 64 + idx];
+        v += red[3 * RM * NT * 64 + idx];
+        const int n = nt * 16 + (ln & 15);
+        const float bv = a.bias[n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + rm * 16 + (ln >> 4) * 4 + j;
+            if (m < a.Mtot) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
+        }
+    }
+}
+
+template <int NT, int RM, bool L0>
+__global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
+    constexpr int PP = NT * 16, BM = 16 * RM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
+    float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp], then 4 private accumulator copies
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
+    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
+    const int n_ex = L0 ? rows_per_wg / S2 : 0;
+    const int mtiles = rows_per_wg / BM;
+    const int64_t wg_m0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
+    const int exsz = a.F * Dp;
+    float* dEw = Es + n_ex * exsz + tap * (n_ex * exsz);
+    float* rs = Es + 5 * n_ex * exsz;
+    const bool fast = L0 && a.lgSo >= 4 && (BM % So) == 0;
+
+    // B fragments: rows (tap, p = nt*16 + r) of W, 4 consecutive q per lane - kept for every m tile
+    float4 bw[NT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float* src = a.W + (int64_t)(tap * PP + nt * 16 + r) * PP + 4 * kk;
+#pragma unroll
+        for (int h = 0; h < NT; ++h) bw[nt][h] = *reinterpret_cast<const float4*>(src + 16 * h);
+    }
+    uint32_t ij[NT];
+    if (L0) {
+        build_pair_lut(lut, a.F, PP);
+        stage_examples(Es, a.Cprev, b0, n_ex, a.B, a.F, a.D, Dp);
+        for (int e = tid; e < 4 * n_ex * exsz; e += 256) Es[n_ex * exsz + e] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ij[nt] = lut[nt * 16 + r];
+    }
+    float accj[RM][NT][4];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accj[rm][nt][j] = 0.f;
+
+    for (int mt = 0; mt < mtiles; ++mt) {
+        const int64_t m0 = wg_m0 + (int64_t)mt * BM;
+        float4 av[RM][NT];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+            int64_t m = m0 + rm * 16 + r;
+            if (m >= a.Mtot) m = a.Mtot - 1;
+#pragma unroll
+            for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(a.dC + m * PP + 16 * h + 4 * kk);
+        }
+        f32x4 acc[RM][NT];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NT; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const float x = t == 0 ? av[rm][h].x : t == 1 ? av[rm][h].y : t == 2 ? av[rm][h].z : av[rm][h].w;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float y = t == 0 ? bw[nt][h].x : t == 1 ? bw[nt][h].y : t == 2 ? bw[nt][h].z : bw[nt][h].w;
+                        acc[rm][nt] = mfma16(x, y, acc[rm][nt]);
+                    }
+                }
+        // ---- epilogue ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+            const int64_t mrow = m0 + rm * 16 + kk * 4;
+            const RowPos rq = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int p = nt * 16 + r;
+                if (!L0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t m = mrow + j;
+                        if (m < a.Mtot) {
+                            const RowPos rp = row_pos(m, a.lgSo);
+                            const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + p;
+                            const float g = acc[rm][nt][j] + a.dt1[(int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y + dh];
+                            a.dprev[pos] = g * act_relu_grad(a.Cprev[pos], a.act);
+                        }
+                    }
+                } else {
+                    const int fi = ij[nt] & 0xffff, fj = ij[nt] >> 16;
+                    const bool pv = p < P;
+                    if (fast) {
+                        const int eb = (rq.b - b0) * exsz;
+                        const float ei = Es[eb + fi * Dp + 2 * rq.y + dh];
+                        float si = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = (pv && mrow + j < a.Mtot) ? acc[rm][nt][j] : 0.f;
+                            si += v * Es[eb + fj * Dp + 2 * (rq.x + j) + dw];
+                            accj[rm][nt][j] += v * ei;
+                        }
+                        si += __shfl_xor(si, 16, 64);
+                        si += __shfl_xor(si, 32, 64);
+                        if (kk == 0 && pv) atomicAdd(&dEw[eb + fi * Dp + 2 * rq.y + dh], si);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t m = mrow + j;
+                            if (pv && m < a.Mtot) {
+                                const RowPos rp = row_pos(m, a.lgSo);
+                                const int eb = (rp.b - b0) * exsz;
+                                const int io = eb + fi * Dp + 2 * rp.y + dh, jo = eb + fj * Dp + 2 * rp.x + dw;
+                                const float v = acc[rm][nt][j];
+                                atomicAdd(&dEw[io], v * Es[jo]);
+                                atomicAdd(&dEw[jo], v * Es[io]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (L0) {
+        if (fast) {   // one example per workgroup and BM % So == 0: x of (rm, kk, j) is the same for every m tile
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) {
+                const int x0 = (rm * 16 + kk * 4) & (So - 1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt * 16 + r < P) {
+                        const int fj = ij[nt] >> 16;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&dEw[fj * Dp + 2 * (x0 + j) + dw], accj[rm][nt][j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* acc0 = Es + n_ex * exsz;
+        float* dots = rs + n_ex * a.F;
+        for (int e = tid; e < n_ex * a.F; e += 256) {
+            const int b = b0 + e / a.F;
+            float s = 0.f, d = 0.f;
+            if (b < a.B)
+                for (int h = 0; h < a.D; ++h) {
+                    const float v = Es[e * Dp + h];
+                    s += v;
+                    d += v * a.dt1[(int64_t)b * a.t1w + h];
+                }
+            rs[e] = s; dots[e] = d;
+        }
+        __syncthreads();
+        const int per = a.F * a.D;
+        const float invD = 1.f / (float)a.D, invF = 1.f / (float)a.F;
+        for (int e = tid; e < n_ex * per; e += 256) {
+            const int row = fast_div(e, invD), h = e - row * a.D, ex = fast_div(row, invF), f = row - ex * a.F, b = b0 + ex;
+            if (b >= a.B) continue;
+            float R = 0.f, Q = 0.f;
+            for (int j = f + 1; j < a.F; ++j) R += rs[ex * a.F + j];
+            for (int i = 0; i < f; ++i) Q += dots[ex * a.F + i];
+            const int o = row * Dp + h, st = n_ex * exsz;
+            const float conv = ((acc0[o] + acc0[st + o]) + acc0[2 * st + o]) + acc0[3 * st + o];
+            a.dprev[(int64_t)b0 * per + e] = conv + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+        }
+    }
+}
+
+// wgrad_taps: wave t accumulates the [PP x PP] weight-gradient block of tap t over the workgroup's chunk of
+// rows.  Both operands are dword fragment loads straight from L2 (A' = act(C_{l-1}) patch channel, B' = dC row),
+// or, for layer 0, A' is generated from the example's embedding tile in LDS.  No barrier inside the row loop.
+template <int NT, bool GEN>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs a) {
+    constexpr int PP = NT * 16, UNR = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // GEN: [PP]
+    float* Es = reinterpret_cast<float*>(lut + PP);           // GEN: [F][Dp] of the current example
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
+    const int slab = blockIdx.x;
+    const int64_t nk = (a.Mtot + 3) / 4;                      // 4-row MFMA k-steps in total
+    const int64_t cps = (nk + gridDim.x - 1) / gridDim.x;
+    const int64_t k_lo = slab * cps, k_hi = min(nk, k_lo + cps);
+
+    f32x4 acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bs[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) bs[q] = 0.f;
+    int fi[NT], fj[NT];
+    if (GEN) {
+        build_pair_lut(lut, a.F, PP);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { const uint32_t ij = lut[i * 16 + r]; fi[i] = (ij & 0xffff) * Dp; fj[i] = (ij >> 16) * Dp; }
+    }
+
+    auto body = [&](int64_t ks, int64_t ke, int bcur) {       // k-steps [ks, ke); GEN: all inside example bcur
+        for (int64_t k0 = ks; k0 < ke; k0 += UNR) {
+            float av[UNR][NT], bv[UNR][NT];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t m = 4 * (k0 + u) + kk;
+                const bool ok = (k0 + u < ke) && m < a.Mtot;
+                const int64_t mm = ok ? m : a.Mtot - 1;
+                const RowPos rp = row_pos(mm, a.lgSo);
+                const float* brow = a.dC + mm * PP + r;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) bv[u][q] = ok ? brow[16 * q] : 0.f;
+                if (GEN) {
+                    const int iy = 2 * rp.y + dh, jx = 2 * rp.x + dw;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) av[u][i] = (i * 16 + r < P) ? Es[fi[i] + iy] * Es[fj[i] + jx] : 0.f;
+                } else {
+                    const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) av[u][i] = act_pos(arow[16 * i], a.act);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) bs[q] += bv[u][q];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(av[u][i], bv[u][q], acc[i][q]);
+            }
+        }
+    };
+
+    if (!GEN) {
+        body(k_lo, k_hi, 0);
+    } else if (k_lo < k_hi) {
+        const int S2 = So * So;
+        const int64_t kpe = S2 / 4 > 0 ? S2 / 4 : 1;           // k-steps per example (S2 >= 4)
+        for (int64_t k0 = k_lo; k0 < k_hi;) {
+            const int b = (int)((4 * k0) >> (2 * a.lgSo));
+            const int64_t kend = min(k_hi, ((int64_t)b + 1) * kpe);
+            __syncthreads();
+            for (int e = tid; e < a.F * a.D; e += 256) {
+                const int f = e / a.D, d = e - f * a.D;
+                Es[f * Dp + d] = a.in[(int64_t)b * a.F * a.D + e];
+            }
+            __syncthreads();
+            body(k0, kend, b);
+            k0 = kend;
+        }
+    }
+    // ---- write this slab -----------------------------------------------------------------------------------
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride + (int64_t)tap * PP * PP;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sw[(i * 16 + kk * 4 + j) * PP + q * 16 + r] = acc[i][q][j];
+    if (tap == 0) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            float v = bs[q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kk == 0) a.slabB[(int64_t)slab * a.slabB_stride + q * 16 + r] = v;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -637,6 +1036,52 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int NT, int RM, bool GEN>
+static int launch_conv_fwd_taps(const ConvArgs& a, hipStream_t st) {
+    constexpr int PP = NT * 16, BM = 16 * RM;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int n_ex = GEN ? (BM > S2 ? BM / S2 : 1) : 0;
+    size_t lds = (size_t)4 * PP * (PP + 4) * 4;
+    const size_t red = (size_t)4 * RM * NT * 64 * 16;
+    if (red > lds) lds = red;
+    lds += (size_t)(GEN ? PP + n_ex * a.F * (a.D + 1) : 0) * 4 + 16;
+    int rc = set_lds(conv_fwd_taps_kernel<NT, RM, GEN>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_fwd_taps_kernel<NT, RM, GEN>), dim3((unsigned)((a.Mtot + BM - 1) / BM)), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT, int RM, bool L0>
+static int launch_dgrad_taps(const DgradArgs& a, hipStream_t st) {
+    constexpr int PP = NT * 16, BM = 16 * RM;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
+    const int n_ex = L0 ? rows_per_wg / S2 : 0;
+    const size_t lds = (size_t)(L0 ? PP + 5 * n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F : 0) * 4 + 16;
+    int rc = set_lds(dgrad_taps_kernel<NT, RM, L0>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((dgrad_taps_kernel<NT, RM, L0>), dim3((unsigned)((a.Mtot + rows_per_wg - 1) / rows_per_wg)), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+#define DISPATCH_NT4(NTV, CALL)                    \
+    switch (NTV) {                                 \
+        case 1: { constexpr int NT_ = 1; CALL; } break; \
+        case 2: { constexpr int NT_ = 2; CALL; } break; \
+        case 3: { constexpr int NT_ = 3; CALL; } break; \
+        default: { constexpr int NT_ = 4; CALL; } break; \
+    }
+
+template <int NT, bool GEN>
+static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
+    const size_t lds = (size_t)(GEN ? NT * 16 + a.F * (a.D + 1) : 0) * 4 + 16;
+    hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN>), dim3(nsl), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline int64_t layer_rows(const Geo& g, int B, int l, int* lgSo) {
     const int So = g.D >> (l + 1);
     *lgSo = ilog2_i(So);
@@ -662,9 +1107,23 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     a.Mtot = layer_rows(g, B, l, &a.lgSo);
     a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
     int nblk, NT;
+    int rc = 0;
+    if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop
+        const int nt4 = g.Pp / 16;
+        const int64_t wg16 = (a.Mtot + 15) / 16;
+        if (l == 0) {
+            if (wg16 >= 4 * 1024) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 4, true>(a, st))); }
+            else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 2, true>(a, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 1, true>(a, st))); }
+        } else {
+            if (wg16 >= 4 * 1024) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 4, false>(a, st))); }
+            else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 2, false>(a, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 1, false>(a, st))); }
+        }
+        return rc;
+    }
     pick_nt(g.Pp / 16, &nblk, &NT);
     const bool big = a.Mtot >= 128 * 256;
-    int rc = 0;
     if (l == 0) {
         if (big) { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 2, true>(a, nblk, st))); }
         else { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 1, true>(a, nblk, st))); }
@@ -688,14 +1147,27 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dC = (const float*)(w + wl.dC[l]);
         a.slabW = gpart + tl.conv_w[l]; a.slabB = gpart + tl.conv_b[l];
-        a.slab_stride = tl.n;
+        a.slab_stride = tl.n; a.slabB_stride = tl.n;
         a.Mtot = layer_rows(g, B, l, &a.lgSo);
         a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
         int NT;
+        if (g.Pp <= 64) {
+            const int nt4 = g.Pp / 16;
+            int nsl = CFFM_NSLAB;
+            if (wl.xslabs[l] > 0) {                          // big layer: finer split into its x-slab scratch
+                nsl = (int)wl.xslabs[l];
+                a.slabW = (float*)(w + wl.xpart[l]); a.slabB = a.slabW + 4 * g.Pp * g.Pp;
+                a.slab_stride = a.slabB_stride = 4 * g.Pp * g.Pp + g.Pp;
+            }
+            if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_wgrad_taps<NT_, true>(a, nsl, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_wgrad_taps<NT_, false>(a, nsl, st))); }
+            if (rc) return rc;
+        } else {
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
         if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
         else { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, false>(a, st))); }
         if (rc) return rc;
+        }
     }
     {   // input gradient
         DgradArgs a;
@@ -708,6 +1180,14 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
         a.t1w = 2 * g.D - 2; a.t1off = t1_offset(g, l);
         int nblk, NT;
+        if (g.Pp <= 64) {
+            const int nt4 = g.Pp / 16;
+            const int64_t wg16 = (a.Mtot + 15) / 16;
+            if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 4, true>(a, st))); }
+            else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 2, false>(a, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 1, false>(a, st))); }
+            return rc;
+        }
         pick_nt(4 * g.Pp / 16, &nblk, &NT);
         const bool big = a.Mtot >= 128 * 256;
         if (l == 0) {

@@ -5,13 +5,14 @@
 // 8 whole rows per instruction (4 rows at 64 floats).  The id of a slot is read by all lanes of that
 // slot (same address -> one broadcast fetch).  The 4-byte feature_bias rows are gathered by a
 // separate slot-per-lane grid tail so that they do not put a divergent scalar load in the row path.
-#include "common.hpp"
+#include "internal.hpp"
 
 template <int UNROLL>
 __global__ __launch_bounds__(256) void gather_rows_kernel(
     const float* __restrict__ inner, const float* __restrict__ outer, const float* __restrict__ fbias,
     const int32_t* __restrict__ ids, int64_t n_slots, int K4, int D4,
-    float* __restrict__ Ei, float* __restrict__ Eo, float* __restrict__ fb, int M) {
+    float* __restrict__ Ei, float* __restrict__ Eo, float* __restrict__ fb, int M,
+    unsigned long long* __restrict__ keys) {
     const int CH = K4 + D4;                       // 16-byte chunks per slot across both tables
     const int64_t total = n_slots * CH;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -47,17 +48,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             else if (which[u] == 1) reinterpret_cast<float4*>(Eo)[dst[u]] = v[u];
         }
     }
-    if (fb != nullptr) {
+    if (fb != nullptr || keys != nullptr) {
         for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
-            int id = ids[s];
-            id = id < 0 ? 0 : (id >= M ? M - 1 : id);
-            fb[s] = fbias[id];
+            const int raw = ids[s];
+            const int id = raw < 0 ? 0 : (raw >= M ? M - 1 : raw);
+            if (fb != nullptr) fb[s] = fbias[id];
+            if (keys != nullptr) keys[s] = ((unsigned long long)(unsigned)raw << 32) | (unsigned long long)s;
         }
     }
 }
 
 extern "C" int cffm_gather(const cffm_shape_t* s, const cffm_tables_t* t, const int32_t* ids, int32_t B,
                            float* Ei, float* Eo, float* fb, void* stream) {
+    return cffm_gather_impl(s, t, ids, B, Ei, Eo, fb, nullptr, (hipStream_t)stream);
+}
+
+int cffm_gather_impl(const cffm_shape_t* s, const cffm_tables_t* t, const int32_t* ids, int32_t B, float* Ei, float* Eo,
+                     float* fb, unsigned long long* keys, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -70,7 +77,7 @@ extern "C" int cffm_gather(const cffm_shape_t* s, const cffm_tables_t* t, const 
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       t->inner_emb, t->outer_emb, t->feat_bias, ids, n_slots, K4, D4, Ei, Eo, fb, s->M);
+                       t->inner_emb, t->outer_emb, t->feat_bias, ids, n_slots, K4, D4, Ei, Eo, fb, s->M, keys);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,7 @@
 //
 // Everything here is tiny per example except the pooling sweep, which re-reads the conv outputs once
 // (contiguous S*Pp-float rows, 16-byte loads) - HBM/L2-bound and bitwise reproducible (fixed tree).
-#include "common.hpp"
+#include "internal.hpp"
 
 struct HeadArgs {
     Geo g;
@@ -145,6 +145,8 @@ struct HeadBwdArgs {
     const float *fb, *t1, *h1, *att, *out, *y, *Ctop;
     const float *d1_w, *d2_w, *att_W, *lin_w;
     float* scalars;
+    const float* sqerr;      // non-NULL: sum the B local loss terms here instead of reading scalars[3]
+    float* loss_out;         // may be NULL
     float *dout, *dt1, *dfb, *dCtop;
     float *s_attW, *s_attb, *s_bias, *s_d1w, *s_d1b, *s_d2w, *s_d2b, *s_linw, *s_linb;   // slab 0 pointers
     int64_t slab_stride;
@@ -160,12 +162,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     const int t1w = 2 * g.D - 2, FF = g.F * g.F;
     const int64_t so = (int64_t)blockIdx.x * a.slab_stride;
     float* s_attW = a.s_attW + so; float* s_d1w = a.s_d1w + so;
-    const float sum = a.scalars[3];
+    float sum;
+    if (a.sqerr) {           // same fixed-order sum in every workgroup
+        float part = 0.f;
+        for (int i = tid; i < a.B; i += 256) part += a.sqerr[i];
+        sum = block_sum(part, red);
+        __syncthreads();
+    } else {
+        sum = a.scalars[3];
+    }
     const float invB = 1.f / (float)a.Bg;
     float L;
     if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
     else L = sum * invB;
-    if (blockIdx.x == 0 && tid == 0) a.scalars[1] = L;
+    if (blockIdx.x == 0 && tid == 0) {
+        a.scalars[1] = L;
+        if (a.sqerr) { a.scalars[0] = sum; a.scalars[3] = sum; }
+        if (a.loss_out) a.loss_out[0] = L;
+    }
     float g_d2w = 0.f, g_d1b = 0.f, g_d2b = 0.f, g_bias = 0.f, g_linw = 0.f, g_linb = 0.f, g_attb = 0.f;
     bool first = true;
     const int off_top = [&] { int o = 0; for (int i = 0; i < g.live; ++i) o += g.D >> i; return o; }();
@@ -257,10 +271,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
         a.s_bias[so] = g_bias;
         a.s_linb[so] = g_linb;
     }
-    (void)red;
 }
 
 extern "C" int cffm_head_fwd(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, void* stream) {
+    return cffm_head_fwd_impl(s, theta, ws, y, B, true, (hipStream_t)stream);
+}
+
+int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum,
+                       hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -282,7 +300,7 @@ extern "C" int cffm_head_fwd(const cffm_shape_t* s, const float* theta, void* ws
     a.loss = s->loss; a.inner_conv = s->inner_conv; a.outer_conv = s->outer_conv;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
-    if (y) {
+    if (y && do_sum) {
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)(w + wl.sqerr),
                            (int64_t)B, (float*)(w + wl.scalars), 1);
         CFFM_CHECK_LAUNCH();
@@ -292,6 +310,11 @@ extern "C" int cffm_head_fwd(const cffm_shape_t* s, const float* theta, void* ws
 
 extern "C" int cffm_head_bwd(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B,
                              int64_t B_global, void* stream) {
+    return cffm_head_bwd_impl(s, theta, ws, y, B, B_global, false, nullptr, (hipStream_t)stream);
+}
+
+int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
+                       bool local_sum, float* loss_out, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -308,6 +331,8 @@ extern "C" int cffm_head_bwd(const cffm_shape_t* s, const float* theta, void* ws
     a.Ctop = (const float*)(w + wl.C[top]); a.dCtop = (float*)(w + wl.dC[top]);
     a.d1_w = theta + tl.d1_w; a.d2_w = theta + tl.d2_w; a.att_W = theta + tl.att_W; a.lin_w = theta + tl.lin_w;
     a.scalars = (float*)(w + wl.scalars);
+    a.sqerr = local_sum ? (const float*)(w + wl.sqerr) : nullptr;
+    a.loss_out = loss_out;
     a.dout = (float*)(w + wl.dout); a.dt1 = (float*)(w + wl.dt1); a.dfb = (float*)(w + wl.dfb);
     a.s_attW = gp + tl.att_W; a.s_attb = gp + tl.att_b; a.s_bias = gp + tl.bias;
     a.s_d1w = gp + tl.d1_w; a.s_d1b = gp + tl.d1_b; a.s_d2w = gp + tl.d2_w; a.s_d2b = gp + tl.d2_b;

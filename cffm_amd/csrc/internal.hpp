@@ -1,0 +1,18 @@
+// Internal (non-ABI) variants used by the fused composites in api.hip.
+#pragma once
+#include "common.hpp"
+
+// gather that also emits the sort keys of the sparse update: keys[slot] = (id << 32) | slot
+int cffm_gather_impl(const cffm_shape_t* s, const cffm_tables_t* t, const int32_t* ids, int32_t B, float* Ei, float* Eo,
+                     float* fb, unsigned long long* keys, hipStream_t st);
+// do_sum = false skips the separate loss-sum launch (cffm_head_bwd_impl then sums the terms itself)
+int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum,
+                       hipStream_t st);
+int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
+                       bool local_sum, float* loss_out, hipStream_t st);
+// theta != nullptr: the dense Adagrad update is fused into the slab reduction
+int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* grad, float* theta, float* acc, float lr,
+                           hipStream_t st);
+int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
+                             const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo, const float* dfb,
+                             void* ws, int32_t B_ws, bool prepacked, hipStream_t st);

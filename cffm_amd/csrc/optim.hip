@@ -6,19 +6,40 @@
 //                   row; rows not in the batch and their accumulators are untouched.  Implemented as a
 //                   stable radix sort of (id, slot) followed by one wavefront per segment head that walks
 //                   its segment in slot order - HBM-bound: per distinct row 5 x (K+D+1) x 4 bytes.
-#include "common.hpp"
+#include "internal.hpp"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+struct XRange { const float* part; int64_t off_w, len_w, off_b, len_b, stride; int nslab; };
+struct XRanges { XRange r[CFFM_MAX_LAYERS]; int n; };
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, int nslab,
-                                                           float* __restrict__ grad) {
+                                                           float* __restrict__ grad, XRanges xs,
+                                                           float* __restrict__ theta, float* __restrict__ acc, float lr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
+    int hit = -1;
+    for (int l = 0; l < xs.n; ++l) {
+        const XRange& x = xs.r[l];
+        if ((i >= x.off_w && i < x.off_w + x.len_w) || (i >= x.off_b && i < x.off_b + x.len_b)) hit = l;
+    }
+    if (hit >= 0) {
+        const XRange& x = xs.r[hit];
+        const int64_t j = i >= x.off_b && i < x.off_b + x.len_b ? x.len_w + (i - x.off_b) : i - x.off_w;
 #pragma unroll 16
-    for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];     // independent loads, fixed add order
+        for (int k = 0; k < x.nslab; ++k) s += x.part[(int64_t)k * x.stride + j];
+    } else {
+#pragma unroll 16
+        for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];     // independent loads, fixed add order
+    }
     grad[i] = s;
+    if (theta != nullptr) {                 // fused dense Adagrad (single-GPU step)
+        const float a = acc[i] + s * s;
+        acc[i] = a;
+        theta[i] -= lr * s / sqrtf(a);
+    }
 }
 
 __global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ v, float* __restrict__ acc,
@@ -31,22 +52,22 @@ __global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ 
     v[i] -= lr * g / sqrtf(a);
 }
 
-__global__ __launch_bounds__(256) void iota_kernel(int32_t* v, int64_t n) {
+__global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restrict__ ids, unsigned long long* keys, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] = (int32_t)i;
+    if (i < n) keys[i] = ((unsigned long long)(unsigned)ids[i] << 32) | (unsigned long long)i;
 }
 
 // one wavefront per sorted position; only segment heads do work
 __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
-    const int32_t* __restrict__ keys, const int32_t* __restrict__ slots, int64_t n, int M, int K, int D,
+    const unsigned long long* __restrict__ keys, int64_t n, int M, int K, int D,
     const float* __restrict__ dEi, const float* __restrict__ dEo, const float* __restrict__ dfb,
     float* __restrict__ inner, float* __restrict__ outer, float* __restrict__ fbias,
     float* __restrict__ a_inner, float* __restrict__ a_outer, float* __restrict__ a_fbias, float lr) {
     const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pos >= n) return;
-    const int id = keys[pos];
-    if (pos > 0 && keys[pos - 1] == id) return;          // not a segment head
+    const int id = (int)(keys[pos] >> 32);
+    if (pos > 0 && (int)(keys[pos - 1] >> 32) == id) return;          // not a segment head
     if (id < 0 || id >= M) return;
     const int W = (dEi ? K : 0) + (dEo ? D : 0) + 1;     // columns: inner | outer | bias
     const int Ki = dEi ? K : 0;
@@ -54,8 +75,10 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
         const int c = c0 + lane;
         float g = 0.f;
         if (c < W) {
-            for (int64_t q = pos; q < n && keys[q] == id; ++q) {
-                const int64_t sl = slots[q];
+            for (int64_t q = pos; q < n; ++q) {
+                const unsigned long long kq = keys[q];
+                if ((int)(kq >> 32) != id) break;
+                const int64_t sl = (int64_t)(kq & 0xffffffffull);
                 g += c < Ki ? dEi[sl * K + c] : (c < W - 1 ? dEo[sl * D + (c - Ki)] : dfb[sl]);
             }
             float *vp, *ap;
@@ -69,14 +92,29 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
     }
 }
 
-extern "C" int cffm_reduce_slabs(const cffm_shape_t* s, void* ws, float* grad, void* stream) {
+extern "C" int cffm_reduce_slabs(const cffm_shape_t* s, void* ws, int32_t B, float* grad, void* stream) {
+    return cffm_reduce_slabs_impl(s, ws, B, grad, nullptr, nullptr, 0.f, (hipStream_t)stream);
+}
+
+int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* grad, float* theta, float* acc, float lr,
+                           hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
-    cffm_theta_layout(s, &tl); cffm_ws_layout(s, 1, &wl);   // gpart sits at a B-independent offset
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const float* gpart = (const float*)((char*)ws + wl.gpart);
+    XRanges x;
+    x.n = 0;
+    for (int l = 0; l < tl.live && s->outer_conv; ++l) {
+        if (wl.xslabs[l] <= 0) continue;
+        const int64_t Pp = tl.Pp;
+        XRange& r = x.r[x.n++];
+        r.part = (const float*)((char*)ws + wl.xpart[l]);
+        r.off_w = tl.conv_w[l]; r.len_w = 4 * Pp * Pp; r.off_b = tl.conv_b[l]; r.len_b = Pp;
+        r.stride = 4 * Pp * Pp + Pp; r.nslab = (int)wl.xslabs[l];
+    }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       gpart, (int64_t)tl.n, (int)CFFM_NSLAB, grad);
+                       gpart, (int64_t)tl.n, (int)CFFM_NSLAB, grad, x, theta, acc, lr);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -92,6 +130,12 @@ extern "C" int cffm_dense_adagrad(float* theta, float* acc, const float* grad, i
 extern "C" int cffm_sparse_adagrad(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
                                    const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo,
                                    const float* dfb, void* ws, int32_t B_ws, void* stream) {
+    return cffm_sparse_adagrad_impl(s, tab, acc, ids, n_rows, dEi, dEo, dfb, ws, B_ws, false, (hipStream_t)stream);
+}
+
+int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
+                             const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo, const float* dfb,
+                             void* ws, int32_t B_ws, bool prepacked, hipStream_t st) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (n_rows <= 0) return 0;
@@ -99,26 +143,25 @@ extern "C" int cffm_sparse_adagrad(const cffm_shape_t* s, const cffm_tables_t* t
     cffm_ws_layout_t wl;
     cffm_ws_layout(s, B_ws, &wl);
     char* w = (char*)ws;
-    hipStream_t st = (hipStream_t)stream;
-    int32_t* keys_out = (int32_t*)(w + wl.sort_keys);
-    int32_t* vals_out = (int32_t*)(w + wl.sort_vals);
-    int32_t* iota = (int32_t*)(w + wl.sort_tmp);
-    const size_t iota_bytes = ((size_t)n_rows * 4 + 255) / 256 * 256;
-    void* tmp = (void*)(w + wl.sort_tmp + iota_bytes);
+    unsigned long long* keys_in = (unsigned long long*)(w + wl.sort_keys);     // (id << 32) | slot
+    unsigned long long* keys_out = (unsigned long long*)(w + wl.sort_vals);
+    void* tmp = (void*)(w + wl.sort_tmp);
     size_t tmp_bytes = 0;
     int bits = 1;
-    while ((1ll << bits) < (long long)s->M && bits < 32) ++bits;
-    hipError_t e = rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, ids, keys_out, (const int32_t*)iota, vals_out,
-                                             (size_t)n_rows, 0u, (unsigned)bits, st);
+    while ((1ll << bits) < (long long)s->M && bits < 31) ++bits;
+    // slots are unique, so sorting the packed keys IS the stable sort by id with slots ascending inside a segment
+    hipError_t e = rocprim::radix_sort_keys((void*)nullptr, tmp_bytes, keys_in, keys_out, (size_t)n_rows, 0u,
+                                            (unsigned)(32 + bits), st);
     if (e != hipSuccess) return (int)e;
-    if (iota_bytes + tmp_bytes > (size_t)wl.sort_tmp_bytes) return CFFM_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, iota, n_rows);
-    CFFM_CHECK_LAUNCH();
-    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, keys_out, (const int32_t*)iota, vals_out, (size_t)n_rows, 0u,
-                                  (unsigned)bits, st);
+    if (tmp_bytes > (size_t)wl.sort_tmp_bytes) return CFFM_ERR_BAD_SHAPE;
+    if (!prepacked) {
+        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ids, keys_in, n_rows);
+        CFFM_CHECK_LAUNCH();
+    }
+    e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, keys_out, (size_t)n_rows, 0u, (unsigned)(32 + bits), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys_out, vals_out,
-                       n_rows, s->M, s->K, s->D, dEi, dEo, dfb, tab->inner_emb, tab->outer_emb, tab->feat_bias,
+    hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys_out, n_rows,
+                       s->M, s->K, s->D, dEi, dEo, dfb, tab->inner_emb, tab->outer_emb, tab->feat_bias,
                        acc->inner_emb, acc->outer_emb, acc->feat_bias, s->lr);
     CFFM_CHECK_LAUNCH();
     return 0;

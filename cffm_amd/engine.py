@@ -66,11 +66,34 @@ class HipEngine(object):
             out.append((self.tl.conv_b[l], 'outer_layer_conv_bias_%d' % l))
         return out
 
+    def _pack(self, name, v):
+        """Reference variable -> its flat image inside theta (conv weights/biases are channel-padded to Pp)."""
+        v = np.asarray(v, dtype=np.float32)
+        P, Pp = self.tl.P, self.tl.Pp
+        if name.startswith('outer_layer_conv_weight_'):
+            out = np.zeros((4, Pp, Pp), dtype=np.float32)
+            out[:, :P, :P] = v.reshape(4, P, P)
+            return out.reshape(-1)
+        if name.startswith('outer_layer_conv_bias_'):
+            out = np.zeros(Pp, dtype=np.float32)
+            out[:P] = v.reshape(-1)
+            return out
+        return v.reshape(-1)
+
+    def _unpack(self, name, flat, off, shp):
+        P, Pp = self.tl.P, self.tl.Pp
+        if name.startswith('outer_layer_conv_weight_'):
+            return flat[off:off + 4 * Pp * Pp].reshape(4, Pp, Pp)[:, :P, :P].reshape(shp).copy()
+        if name.startswith('outer_layer_conv_bias_'):
+            return flat[off:off + P].copy()
+        n = int(np.prod(shp)) if shp else 1
+        return flat[off:off + n].reshape(shp).copy()
+
     def load_params(self, params, accs=None):
         shapes = param_shapes(self.cfg)
         host = np.zeros(int(self.tl.n), dtype=np.float32)
         for off, name in self._members():
-            v = np.asarray(params[name], dtype=np.float32).reshape(-1)
+            v = self._pack(name, params[name])
             host[off:off + v.size] = v
         self.theta.copy_(torch.from_numpy(host))
         self.inner.copy_(torch.from_numpy(np.asarray(params['inner_embeddings'], dtype=np.float32)))
@@ -81,7 +104,9 @@ class HipEngine(object):
         if accs is not None:
             ha = np.full(int(self.tl.n), ADAGRAD_INIT_ACC, dtype=np.float32)
             for off, name in self._members():
-                v = np.asarray(accs[name], dtype=np.float32).reshape(-1)
+                v = self._pack(name, accs[name])
+                if name.startswith('outer_layer_conv_'):
+                    v = np.where(v == 0, np.float32(ADAGRAD_INIT_ACC), v)     # pads keep the initial accumulator
                 ha[off:off + v.size] = v
             self.theta_acc.copy_(torch.from_numpy(ha))
             self.inner_acc.copy_(torch.from_numpy(np.asarray(accs['inner_embeddings'], dtype=np.float32)))
@@ -93,9 +118,7 @@ class HipEngine(object):
         host = flat.detach().cpu().numpy()
         out = {}
         for off, name in self._members():
-            shp = shapes[name]
-            n = int(np.prod(shp)) if shp else 1
-            out[name] = host[off:off + n].reshape(shp).copy()
+            out[name] = self._unpack(name, host, off, shapes[name])
         out['inner_embeddings'] = inner.detach().cpu().numpy().copy()
         out['outer_embeddings'] = outer.detach().cpu().numpy().copy()
         out['feature_bias'] = fbias.detach().cpu().numpy().reshape(-1, 1).copy()

@@ -36,7 +36,8 @@ class WsLayout(C.Structure):
                 ('sqerr', C.c_int64), ('scalars', C.c_int64), ('dout', C.c_int64), ('dt1', C.c_int64),
                 ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
                 ('gpart', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
-                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64)]
+                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('xpart', C.c_int64 * MAX_LAYERS),
+                ('xslabs', C.c_int64 * MAX_LAYERS)]
 
 
 class Tables(C.Structure):
@@ -62,7 +63,7 @@ PROTOTYPES = {
     'cffm_conv_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int32, _P]),
     'cffm_head_fwd': (C.c_int, [_SH, _P, _P, _P, C.c_int32, _P]),
     'cffm_head_bwd': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P]),
-    'cffm_reduce_slabs': (C.c_int, [_SH, _P, _P, _P]),
+    'cffm_reduce_slabs': (C.c_int, [_SH, _P, C.c_int32, _P, _P]),
     'cffm_dense_adagrad': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     'cffm_sparse_adagrad': (C.c_int, [_SH, _TB, _TB, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),
     'cffm_predict': (C.c_int, [_SH, _TB, _P, _P, C.c_int32, _P, _P, _P]),

@@ -67,8 +67,8 @@ typedef struct cffm_theta_layout {
     int64_t bias;                           /* scalar                            CFFM.py:284       */
     int64_t inner_cw, inner_cb;             /* [2 taps][2 ch], [2]               CFFM.py:323       */
     int64_t inner_dw, inner_db;             /* dense [P*K], [1]                  CFFM.py:339       */
-    int64_t conv_w[CFFM_MAX_LAYERS];        /* HWIO [2,2,P,P] = [4P][P]          CFFM.py:375-377   */
-    int64_t conv_b[CFFM_MAX_LAYERS];        /* [P]                                                 */
+    int64_t conv_w[CFFM_MAX_LAYERS];        /* HWIO [2,2,P,P] stored [4][Pp][Pp], zero pads  CFFM.py:375-377 */
+    int64_t conv_b[CFFM_MAX_LAYERS];        /* [Pp], zero pads                                     */
     int64_t d1_w, d1_b;                     /* [2D-2][32], [32]                  CFFM.py:409       */
     int64_t d2_w, d2_b;                     /* [32], [1]                         CFFM.py:410       */
     int64_t lin_w, lin_b;                   /* [F], [1]                          CFFM.py:441       */
@@ -92,6 +92,8 @@ typedef struct cffm_ws_layout {
     int64_t sort_keys, sort_vals;           /* int32 [B*F] each (sorted ids, source slots)         */
     int64_t sort_tmp;                       /* radix sort scratch                                  */
     int64_t sort_tmp_bytes;
+    int64_t xpart[CFFM_MAX_LAYERS];         /* [xslabs[l]][4*Pp*Pp + Pp] finer split-K slabs of a large conv layer */
+    int64_t xslabs[CFFM_MAX_LAYERS];        /* 0: the layer's weight gradient goes straight into gpart            */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
@@ -137,8 +139,9 @@ int cffm_head_fwd(const cffm_shape_t *s, const float *theta, void *ws, const flo
 int cffm_head_bwd(const cffm_shape_t *s, const float *theta, void *ws, const float *y, int32_t B,
                   int64_t B_global, void *stream);
 
-/* sum the CFFM_NSLAB slabs of ws.gpart in slab order -> grad [theta.n] (bitwise reproducible) */
-int cffm_reduce_slabs(const cffm_shape_t *s, void *ws, float *grad, void *stream);
+/* sum the split-K slabs of ws.gpart (and the finer x-slabs of conv layer 0) in slab order -> grad [theta.n];
+ * bitwise reproducible.  B = the batch size the workspace was laid out for. */
+int cffm_reduce_slabs(const cffm_shape_t *s, void *ws, int32_t B, float *grad, void *stream);
 
 /* tf.train.AdagradOptimizer (CFFM.py:523-524), dense: acc += g*g; v -= lr*g/sqrt(acc) over n floats */
 int cffm_dense_adagrad(float *theta, float *acc, const float *grad, int64_t n, float lr, void *stream);
