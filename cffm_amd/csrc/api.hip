@@ -55,7 +55,10 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     int64_t o = 0;
     auto take = [&](int64_t bytes) { int64_t r = o; o += (bytes + 255) / 256 * 256; return r; };
     const int64_t b = B;
-    out->gpart = take((int64_t)CFFM_NSLAB * tl.n * 4);           // first: its offset must not depend on B
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    out->gpart = take(sp.total * 4);                             // first: offset 0
+    out->gpart_floats = sp.total;
     out->scalars = take(16 * 4);
     out->Ei = take(b * g.F * g.K * 4);
     out->Eo = take(b * g.F * g.D * 4);
@@ -84,14 +87,6 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     out->sort_vals = take(nrows * 8);                            // the same keys, sorted
     out->sort_tmp_bytes = nrows * 32 + (4 << 20);
     out->sort_tmp = take(out->sort_tmp_bytes);
-    // big conv layers get a finer split of their weight gradient than CFFM_NSLAB (tap-split path only)
-    for (int l = 0; l < g.live; ++l) {
-        const int64_t S = g.D >> (l + 1);
-        if (s->outer_conv && g.Pp <= 64 && b * S * S >= 256 * 64) {
-            out->xslabs[l] = 256;
-            out->xpart[l] = take((int64_t)256 * (4 * g.Pp * g.Pp + g.Pp) * 4);
-        }
-    }
     out->bytes = o;
     return 0;
 }
@@ -147,7 +142,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
     const Geo g = make_geo(s);
     char* w = (char*)ws;
     if (!s->inner_conv || !s->outer_conv || !s->linear_att) {   // slabs of a disabled branch must read as zeros
-        hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)CFFM_NSLAB * tl.n * 4, stream);
+        hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)wl.gpart_floats * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
     if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused, loss_out, stream))) return rc;

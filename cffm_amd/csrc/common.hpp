@@ -48,6 +48,46 @@ static inline int check_shape(const cffm_shape_t* s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-K gradient slabs.  Every dense-gradient producer writes per-workgroup partial sums ("slabs") that
+// cffm_reduce_slabs adds up in slab order.  theta is cut into contiguous ranges, each with its own slab
+// count: the small head / inner ranges get one slab per example (up to 256), a conv layer gets CFFM_NSLAB or,
+// when it has many rows, 256.  Range r keeps its slabs at gpart + base: [nslab][len] floats.
+// ---------------------------------------------------------------------------------------------
+#define CFFM_NSLAB_SMALL 256
+struct SlabRange { int64_t off, len, base; int nslab; };
+struct SlabPlan {
+    SlabRange r[CFFM_MAX_LAYERS + 3];
+    int n;
+    int64_t total;                       // floats
+    int head_front, inner, conv0, head_back;   // indices into r
+};
+
+static inline int conv_slabs(const cffm_shape_t* s, int32_t B, int l) {
+    const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
+    const int64_t S = s->D >> (l + 1);
+    return (Pp <= 64 && (int64_t)B * S * S >= 256 * 64) ? 256 : CFFM_NSLAB;
+}
+
+static inline void make_slab_plan(const cffm_shape_t* s, int32_t B, const cffm_theta_layout_t& tl, SlabPlan* p) {
+    int n = 0;
+    int64_t base = 0;
+    auto add = [&](int64_t off, int64_t end, int nslab) {
+        p->r[n].off = off; p->r[n].len = end - off; p->r[n].base = base; p->r[n].nslab = nslab;
+        base += (end - off) * nslab;
+        return n++;
+    };
+    const int64_t convs = tl.live > 0 ? tl.conv_w[0] : tl.d1_w;
+    p->head_front = add(0, tl.inner_cw, CFFM_NSLAB_SMALL);
+    p->inner = add(tl.inner_cw, convs, CFFM_NSLAB_SMALL);
+    p->conv0 = n;
+    for (int l = 0; l < tl.live; ++l)
+        add(tl.conv_w[l], l + 1 < tl.live ? tl.conv_w[l + 1] : tl.d1_w, conv_slabs(s, B, l));
+    p->head_back = add(tl.d1_w, tl.n, CFFM_NSLAB_SMALL);
+    p->n = n;
+    p->total = base;
+}
+
+// ---------------------------------------------------------------------------------------------
 // activations, TF-1.14 functor semantics
 // ---------------------------------------------------------------------------------------------
 #define CFFM_SELU_SCALE 1.0507009873554804934193349852946f

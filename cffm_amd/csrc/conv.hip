@@ -1030,7 +1030,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * 80) + 4) * 4;
     int rc = set_lds(wgrad_kernel<NT, GEN>, lds);
     if (rc) return rc;
-    dim3 grid((unsigned)((4 * a.Pp / 64) * a.qblocks), CFFM_NSLAB);
+    dim3 grid((unsigned)((4 * a.Pp / 64) * a.qblocks), CFFM_NSLAB);   // Pp > 64: conv_slabs() == CFFM_NSLAB
     hipLaunchKernelGGL((wgrad_kernel<NT, GEN>), grid, dim3(256), lds, st, a);
     CFFM_CHECK_LAUNCH();
     return 0;
@@ -1141,24 +1141,22 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     if (l < 0 || l >= g.live) return CFFM_ERR_BAD_SHAPE;
     char* w = (char*)ws;
     float* gpart = (float*)(w + wl.gpart);
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const SlabRange& sr = sp.r[sp.conv0 + l];
     int rc = 0;
     {   // weight / bias gradient
         WgradArgs a;
         a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dC = (const float*)(w + wl.dC[l]);
-        a.slabW = gpart + tl.conv_w[l]; a.slabB = gpart + tl.conv_b[l];
-        a.slab_stride = tl.n; a.slabB_stride = tl.n;
+        a.slabW = gpart + sr.base; a.slabB = a.slabW + (tl.conv_b[l] - tl.conv_w[l]);
+        a.slab_stride = sr.len; a.slabB_stride = sr.len;
         a.Mtot = layer_rows(g, B, l, &a.lgSo);
         a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
         int NT;
         if (g.Pp <= 64) {
             const int nt4 = g.Pp / 16;
-            int nsl = CFFM_NSLAB;
-            if (wl.xslabs[l] > 0) {                          // big layer: finer split into its x-slab scratch
-                nsl = (int)wl.xslabs[l];
-                a.slabW = (float*)(w + wl.xpart[l]); a.slabB = a.slabW + 4 * g.Pp * g.Pp;
-                a.slab_stride = a.slabB_stride = 4 * g.Pp * g.Pp + g.Pp;
-            }
+            const int nsl = sr.nslab;
             if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_wgrad_taps<NT_, true>(a, nsl, st))); }
             else { DISPATCH_NT4(nt4, rc = (launch_wgrad_taps<NT_, false>(a, nsl, st))); }
             if (rc) return rc;

@@ -149,7 +149,8 @@ struct HeadBwdArgs {
     float* loss_out;         // may be NULL
     float *dout, *dt1, *dfb, *dCtop;
     float *s_attW, *s_attb, *s_bias, *s_d1w, *s_d1b, *s_d2w, *s_d2b, *s_linw, *s_linb;   // slab 0 pointers
-    int64_t slab_stride;
+    int64_t stride_front, stride_back;    // slab strides of the head-front (att_W, att_b, bias) and head-back ranges
+    int64_t front_len, back_len;
     int loss, outer_conv;
 };
 
@@ -160,8 +161,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t1w = 2 * g.D - 2, FF = g.F * g.F;
-    const int64_t so = (int64_t)blockIdx.x * a.slab_stride;
-    float* s_attW = a.s_attW + so; float* s_d1w = a.s_d1w + so;
+    const int64_t sof = (int64_t)blockIdx.x * a.stride_front, sob = (int64_t)blockIdx.x * a.stride_back;
+    float* s_attW = a.s_attW + sof; float* s_d1w = a.s_d1w + sob;
+    // zero this slab's two ranges first (alignment gaps and members this configuration never writes)
+    for (int64_t e = tid; e < a.front_len; e += 256) s_attW[e] = 0.f;        // att_W is the first member of the range
+    for (int64_t e = tid; e < a.back_len; e += 256) s_d1w[e] = 0.f;          // d1_w is the first member of the range
+    __syncthreads();
     float sum;
     if (a.sqerr) {           // same fixed-order sum in every workgroup
         float part = 0.f;
@@ -254,22 +259,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
         }
         first = false;
     }
-    if (first) {
-        for (int e = tid; e < t1w * CFFM_HEAD_UNITS; e += 256) s_d1w[e] = 0.f;
-        for (int e = tid; e < FF; e += 256) s_attW[e] = 0.f;
-    }
+    (void)FF;
     if (tid < CFFM_HEAD_UNITS) {
-        a.s_d2w[so + tid] = g_d2w;
-        a.s_d1b[so + tid] = g_d1b;
+        a.s_d2w[sob + tid] = g_d2w;
+        a.s_d1b[sob + tid] = g_d1b;
     }
     if (tid < g.F) {
-        a.s_linw[so + tid] = g_linw;
-        a.s_attb[so + tid] = g_attb;
+        a.s_linw[sob + tid] = g_linw;
+        a.s_attb[sof + tid] = g_attb;
     }
     if (tid == 0) {
-        a.s_d2b[so] = g_d2b;
-        a.s_bias[so] = g_bias;
-        a.s_linb[so] = g_linb;
+        a.s_d2b[sob] = g_d2b;
+        a.s_bias[sof] = g_bias;
+        a.s_linb[sob] = g_linb;
     }
 }
 
@@ -322,7 +324,12 @@ int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
-    float* gp = (float*)(w + wl.gpart);
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const SlabRange& rf = sp.r[sp.head_front];
+    const SlabRange& rb = sp.r[sp.head_back];
+    float* gf = (float*)(w + wl.gpart) + rf.base - rf.off;        // slab 0 of theta offset x lives at gf + x
+    float* gb = (float*)(w + wl.gpart) + rb.base - rb.off;
     HeadBwdArgs a;
     a.g = make_geo(s); a.B = B; a.Bg = B_global;
     a.fb = (const float*)(w + wl.fb); a.t1 = (const float*)(w + wl.t1); a.h1 = (const float*)(w + wl.h1);
@@ -334,12 +341,12 @@ int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     a.sqerr = local_sum ? (const float*)(w + wl.sqerr) : nullptr;
     a.loss_out = loss_out;
     a.dout = (float*)(w + wl.dout); a.dt1 = (float*)(w + wl.dt1); a.dfb = (float*)(w + wl.dfb);
-    a.s_attW = gp + tl.att_W; a.s_attb = gp + tl.att_b; a.s_bias = gp + tl.bias;
-    a.s_d1w = gp + tl.d1_w; a.s_d1b = gp + tl.d1_b; a.s_d2w = gp + tl.d2_w; a.s_d2b = gp + tl.d2_b;
-    a.s_linw = gp + tl.lin_w; a.s_linb = gp + tl.lin_b;
-    a.slab_stride = tl.n;
+    a.s_attW = gf + tl.att_W; a.s_attb = gf + tl.att_b; a.s_bias = gf + tl.bias;
+    a.s_d1w = gb + tl.d1_w; a.s_d1b = gb + tl.d1_b; a.s_d2w = gb + tl.d2_w; a.s_d2b = gb + tl.d2_b;
+    a.s_linw = gb + tl.lin_w; a.s_linb = gb + tl.lin_b;
+    a.stride_front = rf.len; a.stride_back = rb.len; a.front_len = rf.len; a.back_len = rb.len;
     a.loss = s->loss; a.outer_conv = s->outer_conv;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(CFFM_NSLAB), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(CFFM_NSLAB_SMALL), dim3(256), 0, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(256) void inner_bwd_kernel(Geo g, int B, const floa
     float* red = reinterpret_cast<float*>(lut + g.Pp);         // [4]
     const int wave = threadIdx.x >> 6;
     build_pair_lut(lut, g.F, g.Pp);
+    // alignment gaps of this slab range must read as zeros in the reduction
+    if (threadIdx.x < 8) slab_cw[threadIdx.x] = 0.f;          // inner_cw (4) + inner_cb (2 + 2 pad)
+    if (threadIdx.x < 4) slab_db[threadIdx.x] = 0.f;          // inner_db (1 + 3 pad)
     float cw[4] = {cw_g[0], cw_g[1], cw_g[2], cw_g[3]};
     float cb[2] = {cb_g[0], cb_g[1]};
     const int K2 = g.K / 2, units = g.P * K2;
@@ -168,12 +171,14 @@ extern "C" int cffm_inner_bwd(const cffm_shape_t* s, const float* theta, void* w
         hipError_t e = hipFuncSetAttribute((const void*)inner_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    float* gpart = (float*)(w + wl.gpart);
-    // slab s of parameter x lives at gpart + s * tl.n + offset(x)
-    hipLaunchKernelGGL(inner_bwd_kernel, dim3(CFFM_NSLAB), dim3(256), lds, (hipStream_t)stream, g, (int)B,
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const SlabRange& sr = sp.r[sp.inner];
+    float* base = (float*)(w + wl.gpart) + sr.base - sr.off;      // slab 0 of theta offset x lives at base + x
+    hipLaunchKernelGGL(inner_bwd_kernel, dim3(sr.nslab), dim3(256), lds, (hipStream_t)stream, g, (int)B,
                        (const float*)(w + wl.Ei), (const float*)(w + wl.dout), theta + tl.inner_cw,
-                       theta + tl.inner_cb, theta + tl.inner_dw, (float*)(w + wl.dEi), gpart + tl.inner_cw,
-                       gpart + tl.inner_cb, gpart + tl.inner_dw, gpart + tl.inner_db, (int64_t)tl.n);
+                       theta + tl.inner_cb, theta + tl.inner_dw, (float*)(w + wl.dEi), base + tl.inner_cw,
+                       base + tl.inner_cb, base + tl.inner_dw, base + tl.inner_db, (int64_t)sr.len);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

@@ -11,29 +11,19 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
-struct XRange { const float* part; int64_t off_w, len_w, off_b, len_b, stride; int nslab; };
-struct XRanges { XRange r[CFFM_MAX_LAYERS]; int n; };
-
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, int nslab,
-                                                           float* __restrict__ grad, XRanges xs,
-                                                           float* __restrict__ theta, float* __restrict__ acc, float lr) {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
+                                                           float* __restrict__ grad, float* __restrict__ theta,
+                                                           float* __restrict__ acc, float lr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    int hit = 0;
+    for (int r = 1; r < sp.n; ++r)
+        if (i >= sp.r[r].off) hit = r;
+    const SlabRange rg = sp.r[hit];
+    const float* src = gpart + rg.base + (i - rg.off);
     float s = 0.f;
-    int hit = -1;
-    for (int l = 0; l < xs.n; ++l) {
-        const XRange& x = xs.r[l];
-        if ((i >= x.off_w && i < x.off_w + x.len_w) || (i >= x.off_b && i < x.off_b + x.len_b)) hit = l;
-    }
-    if (hit >= 0) {
-        const XRange& x = xs.r[hit];
-        const int64_t j = i >= x.off_b && i < x.off_b + x.len_b ? x.len_w + (i - x.off_b) : i - x.off_w;
 #pragma unroll 16
-        for (int k = 0; k < x.nslab; ++k) s += x.part[(int64_t)k * x.stride + j];
-    } else {
-#pragma unroll 16
-        for (int k = 0; k < nslab; ++k) s += gpart[(int64_t)k * n + i];     // independent loads, fixed add order
-    }
+    for (int k = 0; k < rg.nslab; ++k) s += src[(int64_t)k * rg.len];      // independent loads, fixed add order
     grad[i] = s;
     if (theta != nullptr) {                 // fused dense Adagrad (single-GPU step)
         const float a = acc[i] + s * s;
@@ -102,19 +92,11 @@ int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* gr
     if (rc) return rc;
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
     const float* gpart = (const float*)((char*)ws + wl.gpart);
-    XRanges x;
-    x.n = 0;
-    for (int l = 0; l < tl.live && s->outer_conv; ++l) {
-        if (wl.xslabs[l] <= 0) continue;
-        const int64_t Pp = tl.Pp;
-        XRange& r = x.r[x.n++];
-        r.part = (const float*)((char*)ws + wl.xpart[l]);
-        r.off_w = tl.conv_w[l]; r.len_w = 4 * Pp * Pp; r.off_b = tl.conv_b[l]; r.len_b = Pp;
-        r.stride = 4 * Pp * Pp + Pp; r.nslab = (int)wl.xslabs[l];
-    }
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       gpart, (int64_t)tl.n, (int)CFFM_NSLAB, grad, x, theta, acc, lr);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, stream, gpart,
+                       (int64_t)tl.n, sp, grad, theta, acc, lr);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

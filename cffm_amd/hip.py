@@ -35,9 +35,8 @@ class WsLayout(C.Structure):
                 ('t1', C.c_int64), ('h1', C.c_int64), ('att', C.c_int64), ('out', C.c_int64),
                 ('sqerr', C.c_int64), ('scalars', C.c_int64), ('dout', C.c_int64), ('dt1', C.c_int64),
                 ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
-                ('gpart', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
-                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('xpart', C.c_int64 * MAX_LAYERS),
-                ('xslabs', C.c_int64 * MAX_LAYERS)]
+                ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
+                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64)]
 
 
 class Tables(C.Structure):

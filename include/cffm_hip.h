@@ -88,12 +88,11 @@ typedef struct cffm_ws_layout {
     int64_t dout, dt1;                      /* [B], [B,2D-2]                                       */
     int64_t dC[CFFM_MAX_LAYERS];            /* grad wrt C_l, same shape as C_l                     */
     int64_t dEi, dEo, dfb;                  /* IndexedSlices values [B,F,K] [B,F,D] [B,F]          */
-    int64_t gpart;                          /* [CFFM_NSLAB][theta.n] split-K partial gradients     */
+    int64_t gpart;                          /* split-K partial gradients, per theta range [nslab][len] */
+    int64_t gpart_floats;
     int64_t sort_keys, sort_vals;           /* int32 [B*F] each (sorted ids, source slots)         */
     int64_t sort_tmp;                       /* radix sort scratch                                  */
     int64_t sort_tmp_bytes;
-    int64_t xpart[CFFM_MAX_LAYERS];         /* [xslabs[l]][4*Pp*Pp + Pp] finer split-K slabs of a large conv layer */
-    int64_t xslabs[CFFM_MAX_LAYERS];        /* 0: the layer's weight gradient goes straight into gpart            */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */

@@ -41,7 +41,8 @@ def test_theta_layout_matches_reference_variable_sizes(lib):
                ('inner_dw', 'dense_kernel'), ('d1_w', 'dense_1_kernel'), ('d2_w', 'dense_2_kernel'),
                ('lin_w', 'dense_3_kernel')]
     spans = [(getattr(tl, m), int(np.prod(shapes[n]))) for m, n in members]
-    spans += [(tl.conv_w[l], 4 * 45 * 45) for l in range(tl.live)] + [(tl.conv_b[l], 45) for l in range(tl.live)]
+    # conv weights / biases are stored channel-padded: [4][Pp][Pp] and [Pp]
+    spans += [(tl.conv_w[l], 4 * 48 * 48) for l in range(tl.live)] + [(tl.conv_b[l], 48) for l in range(tl.live)]
     spans += [(tl.bias, 1), (tl.inner_cb, 2), (tl.inner_db, 1), (tl.d1_b, 32), (tl.d2_b, 1), (tl.lin_b, 1)]
     spans.sort()
     for (o0, n0), (o1, _) in zip(spans, spans[1:]):
@@ -51,7 +52,8 @@ def test_theta_layout_matches_reference_variable_sizes(lib):
     trained = sum(int(np.prod(s)) if s else 1 for k, s in shapes.items()
                   if k not in ('inner_embeddings', 'outer_embeddings', 'feature_bias', 'outer_W', 'outer_b')
                   and not k.endswith('_%d' % (cfg.Lc - 1)))
-    assert trained <= tl.n < trained + 4 * len(spans)
+    pad = tl.live * (4 * (48 * 48 - 45 * 45) + 3)
+    assert trained + pad <= tl.n < trained + pad + 4 * len(spans)
 
 
 def test_workspace_layout(lib):
