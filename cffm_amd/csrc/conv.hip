@@ -688,13 +688,134 @@ __global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
     }
 }
 
-template <int NT, int RM, bool L0>
-__global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
-    constexpr int PP = NT * 16, BM = 16 * RM;
+// conv_fwd_rows: many-row variant of the small-Pp forward (layer 0 at frappe: 65536 rows).  The whole padded
+// filter [4*PP][PP] is staged once into LDS (36 KB at PP = 48, one barrier); each wavefront then runs all four
+// taps over its own 16*RM rows, so there is no cross-wave reduction and the epilogue comes straight from the
+// accumulators.
+template <int NT, int RM, bool GEN>
+__global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
+    constexpr int PP = NT * 16, LDW = PP + 4, BM = 64 * RM;
+    constexpr int NW4 = 4 * PP * PP / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][LDW]
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
+    float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int b0 = (int)(m0 >> (2 * a.lgSo));
+
+    float4 wv[NW4];
+    const float4* wsrc = reinterpret_cast<const float4*>(a.W);
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) wv[i] = wsrc[tid + 256 * i];
+    float4 av[RM][4][NT];
+    int iy[RM], jx[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+        int64_t m = m0 + wave * (16 * RM) + rm * 16 + r;
+        if (m >= a.Mtot) m = a.Mtot - 1;
+        const RowPos rp = row_pos(m, a.lgSo);
+        if (GEN) {
+            const int eoff = (rp.b - b0) * a.F * Dp;
+            iy[rm] = eoff + 2 * rp.y;
+            jx[rm] = eoff + 2 * rp.x;
+        } else {
+            const float* src = a.in + (((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * PP + 4 * kk;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+                for (int h = 0; h < NT; ++h)
+                    av[rm][tap][h] = *reinterpret_cast<const float4*>(src + ((tap >> 1) * Sin + (tap & 1)) * PP + 16 * h);
+        }
+    }
+    if (GEN) {
+        const int S2 = So * So;
+        const int n_ex = BM > S2 ? BM / S2 : 1;
+        build_pair_lut(lut, a.F, PP);
+        stage_examples(Es, a.in, b0, n_ex, a.B, a.F, a.D, Dp);
+    }
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+        const int u = tid + 256 * i, row = u / (PP / 4), c4 = u % (PP / 4);
+        *reinterpret_cast<float4*>(&Wl[row * LDW + 4 * c4]) = wv[i];
+    }
+    __syncthreads();
+
+    f32x4 acc[RM][NT];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        const int dh = tap >> 1, dw = tap & 1;
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+            float4 x4[RM];
+            if (GEN) {
+                const uint4 l4 = *reinterpret_cast<const uint4*>(&lut[16 * h + 4 * kk]);
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const int i0 = iy[rm] + dh, j0 = jx[rm] + dw;
+                    x4[rm].x = Es[i0 + (l4.x & 0xffff) * Dp] * Es[j0 + (l4.x >> 16) * Dp];
+                    x4[rm].y = Es[i0 + (l4.y & 0xffff) * Dp] * Es[j0 + (l4.y >> 16) * Dp];
+                    x4[rm].z = Es[i0 + (l4.z & 0xffff) * Dp] * Es[j0 + (l4.z >> 16) * Dp];
+                    x4[rm].w = Es[i0 + (l4.w & 0xffff) * Dp] * Es[j0 + (l4.w >> 16) * Dp];
+                }
+            } else {
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    x4[rm].x = act_pos(av[rm][tap][h].x, a.act); x4[rm].y = act_pos(av[rm][tap][h].y, a.act);
+                    x4[rm].z = act_pos(av[rm][tap][h].z, a.act); x4[rm].w = act_pos(av[rm][tap][h].w, a.act);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int krow = tap * PP + 16 * h + 4 * kk + t;
+                float bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = Wl[krow * LDW + nt * 16 + r];
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const float x = t == 0 ? x4[rm].x : t == 1 ? x4[rm].y : t == 2 ? x4[rm].z : x4[rm].w;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = mfma16(x, bf[nt], acc[rm][nt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + r;
+            const float bv = a.bias[n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                if (m < a.Mtot) a.out[m * PP + n] = fmaxf(acc[rm][nt][j] + bv, 0.f);
+            }
+        }
+}
+
+// HALVES = 2 (layer 0 only): 8 wavefronts, the upper four take the second half of the workgroup's m tiles, so
+// that every SIMD has two wavefronts whose MFMA and epilogue phases can overlap.
+//
+// Layer 0 "fast" path (So >= 16, one example per workgroup): no LDS atomics at all.  A 16-row tile is 16
+// consecutive x of one (b, y).  i-side: the tile's contribution to dEo[i_p][2y+dh] is reduced over x in
+// registers + two cross-lane adds and STORED at Ti[tap][p][y] (each (tap, p, y) is produced exactly once).
+// j-side: dEo[j_p][2x+dw] sums over y, which the lane keeps in registers across its m tiles and stores at
+// Tj[half][tap][p][x].  A final pass adds, for every (field, h), the Ti / Tj entries of the pairs that contain
+// the field, in pair order: bitwise reproducible, and ~100x cheaper than ds_add_f32 (measured: the atomic
+// version spent 83 K LDS cycles per CU).
+template <int NT, int RM, bool L0, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
+    constexpr int PP = NT * 16, BM = 16 * RM, NTH = 256 * HALVES, NCOPY = 4 * HALVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
-    float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp], then 4 private accumulator copies
-    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
@@ -702,9 +823,12 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
     const int64_t wg_m0 = (int64_t)blockIdx.x * rows_per_wg;
     const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
     const int exsz = a.F * Dp;
-    float* dEw = Es + n_ex * exsz + tap * (n_ex * exsz);
-    float* rs = Es + 5 * n_ex * exsz;
-    const bool fast = L0 && a.lgSo >= 4 && (BM % So) == 0;
+    const bool fast = L0 && RM == 4 && a.lgSo >= 4 && a.lgSo <= 6;      // tiles per y = So/16 divides RM
+    float* rs = Es + n_ex * exsz;                               // [n_ex][F] row sums, then [n_ex][F] dots
+    float* scratch = rs + 2 * n_ex * a.F;
+    float* dEw = scratch + wid * (n_ex * exsz);                // slow path: this wave's private accumulators
+    float* Ti = scratch;                                        // fast path: [4][PP][So]
+    float* Tj = Ti + 4 * PP * So;                               //            [HALVES][4][PP][So]
 
     // B fragments: rows (tap, p = nt*16 + r) of W, 4 consecutive q per lane - kept for every m tile
     float4 bw[NT][NT];
@@ -718,7 +842,8 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
     if (L0) {
         build_pair_lut(lut, a.F, PP);
         stage_examples(Es, a.Cprev, b0, n_ex, a.B, a.F, a.D, Dp);
-        for (int e = tid; e < 4 * n_ex * exsz; e += 256) Es[n_ex * exsz + e] = 0.f;
+        if (!fast)
+            for (int e = tid; e < NCOPY * n_ex * exsz; e += NTH) scratch[e] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) ij[nt] = lut[nt * 16 + r];
@@ -731,7 +856,10 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) accj[rm][nt][j] = 0.f;
 
-    for (int mt = 0; mt < mtiles; ++mt) {
+    const int mt_per = (mtiles + HALVES - 1) / HALVES;
+    const int mt_lo = half * mt_per, mt_hi = min(mtiles, mt_lo + mt_per);
+    const int tpy = So >> 4;                                    // fast path: 16-row tiles per y
+    for (int mt = mt_lo; mt < mt_hi; ++mt) {
         const int64_t m0 = wg_m0 + (int64_t)mt * BM;
         float4 av[RM][NT];
 #pragma unroll
@@ -760,6 +888,9 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
                     }
                 }
         // ---- epilogue ----------------------------------------------------------------------------------
+        float si_run[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) si_run[nt] = 0.f;
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             const int64_t mrow = m0 + rm * 16 + kk * 4;
@@ -782,18 +913,21 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
                     const int fi = ij[nt] & 0xffff, fj = ij[nt] >> 16;
                     const bool pv = p < P;
                     if (fast) {
-                        const int eb = (rq.b - b0) * exsz;
-                        const float ei = Es[eb + fi * Dp + 2 * rq.y + dh];
+                        const float ei = Es[fi * Dp + 2 * rq.y + dh];
                         float si = 0.f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = (pv && mrow + j < a.Mtot) ? acc[rm][nt][j] : 0.f;
-                            si += v * Es[eb + fj * Dp + 2 * (rq.x + j) + dw];
+                            si += v * Es[fj * Dp + 2 * (rq.x + j) + dw];
                             accj[rm][nt][j] += v * ei;
                         }
                         si += __shfl_xor(si, 16, 64);
                         si += __shfl_xor(si, 32, 64);
-                        if (kk == 0 && pv) atomicAdd(&dEw[eb + fi * Dp + 2 * rq.y + dh], si);
+                        si_run[nt] += si;
+                        if (((rm + 1) & (tpy - 1)) == 0) {       // last tile of this y
+                            if (kk == 0) Ti[(tap * PP + p) * So + rq.y] = si_run[nt];
+                            si_run[nt] = 0.f;
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -813,24 +947,29 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
         }
     }
     if (L0) {
-        if (fast) {   // one example per workgroup and BM % So == 0: x of (rm, kk, j) is the same for every m tile
+        if (fast) {   // x of (rm, kk, j) is the same for every m tile: x = (rm*16 + kk*4 + j) & (So - 1)
+            float* tj = Tj + (half * 4 + tap) * PP * So;
 #pragma unroll
-            for (int rm = 0; rm < RM; ++rm) {
-                const int x0 = (rm * 16 + kk * 4) & (So - 1);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int p = nt * 16 + r;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (nt * 16 + r < P) {
-                        const int fj = ij[nt] >> 16;
+                for (int j = 0; j < 4; ++j) {
+                    const int xb = kk * 4 + j;
+                    if (a.lgSo == 4) {
+                        tj[p * So + xb] = ((accj[0][nt][j] + accj[1][nt][j]) + accj[2][nt][j]) + accj[3][nt][j];
+                    } else if (a.lgSo == 5) {
+                        tj[p * So + xb] = accj[0][nt][j] + accj[2][nt][j];
+                        tj[p * So + 16 + xb] = accj[1][nt][j] + accj[3][nt][j];
+                    } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) atomicAdd(&dEw[fj * Dp + 2 * (x0 + j) + dw], accj[rm][nt][j]);
+                        for (int rm = 0; rm < RM; ++rm) tj[p * So + rm * 16 + xb] = accj[rm][nt][j];
                     }
                 }
             }
         }
         __syncthreads();
-        float* acc0 = Es + n_ex * exsz;
         float* dots = rs + n_ex * a.F;
-        for (int e = tid; e < n_ex * a.F; e += 256) {
+        for (int e = tid; e < n_ex * a.F; e += NTH) {
             const int b = b0 + e / a.F;
             float s = 0.f, d = 0.f;
             if (b < a.B)
@@ -844,29 +983,54 @@ __global__ __launch_bounds__(256) void dgrad_taps_kernel(DgradArgs a) {
         __syncthreads();
         const int per = a.F * a.D;
         const float invD = 1.f / (float)a.D, invF = 1.f / (float)a.F;
-        for (int e = tid; e < n_ex * per; e += 256) {
+        for (int e = tid; e < n_ex * per; e += NTH) {
             const int row = fast_div(e, invD), h = e - row * a.D, ex = fast_div(row, invF), f = row - ex * a.F, b = b0 + ex;
             if (b >= a.B) continue;
             float R = 0.f, Q = 0.f;
             for (int j = f + 1; j < a.F; ++j) R += rs[ex * a.F + j];
             for (int i = 0; i < f; ++i) Q += dots[ex * a.F + i];
-            const int o = row * Dp + h, st = n_ex * exsz;
-            const float conv = ((acc0[o] + acc0[st + o]) + acc0[2 * st + o]) + acc0[3 * st + o];
+            float conv = 0.f;
+            if (fast) {
+                const int hh = h >> 1, lo = h & 1;               // h = 2y+dh on the i-side, 2x+dw on the j-side
+                const int base_f = f * (2 * a.F - f - 1) / 2;
+                for (int j = f + 1; j < a.F; ++j) {              // pairs (f, j): f is the i field
+                    const int p = base_f + j - f - 1;
+                    conv += Ti[((lo * 2 + 0) * PP + p) * So + hh];
+                    conv += Ti[((lo * 2 + 1) * PP + p) * So + hh];
+                }
+                for (int i = 0; i < f; ++i) {                    // pairs (i, f): f is the j field
+                    const int p = i * (2 * a.F - i - 1) / 2 + f - i - 1;
+#pragma unroll
+                    for (int hf = 0; hf < HALVES; ++hf) {
+                        conv += Tj[((hf * 4 + 0 + lo) * PP + p) * So + hh];
+                        conv += Tj[((hf * 4 + 2 + lo) * PP + p) * So + hh];
+                    }
+                }
+            } else {
+                const int o = row * Dp + h, st = n_ex * exsz;
+                conv = scratch[o];
+#pragma unroll
+                for (int c = 1; c < NCOPY; ++c) conv += scratch[c * st + o];
+            }
             a.dprev[(int64_t)b0 * per + e] = conv + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
         }
     }
 }
 
-// wgrad_taps: wave t accumulates the [PP x PP] weight-gradient block of tap t over the workgroup's chunk of
-// rows.  Both operands are dword fragment loads straight from L2 (A' = act(C_{l-1}) patch channel, B' = dC row),
-// or, for layer 0, A' is generated from the example's embedding tile in LDS.  No barrier inside the row loop.
-template <int NT, bool GEN>
-__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs a) {
-    constexpr int PP = NT * 16, UNR = 4;
+// wgrad_taps: wave t accumulates the [PP x PP] weight-gradient block of tap t over its share of the
+// workgroup's chunk of rows.  Both operands are dword fragment loads straight from L2 (A' = act(C_{l-1}) patch
+// channel, B' = dC row), or, for layer 0, A' is generated from the example's embedding tile in LDS.  A
+// workgroup has 4*HALVES wavefronts: with HALVES = 2 the chunk is cut in two and the two partial blocks of a
+// tap are added (lower half first) through LDS.  Loads of step i+1 are issued before the MFMAs of step i.
+template <int NT, bool GEN, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
+    constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // GEN: [PP]
-    float* Es = reinterpret_cast<float*>(lut + PP);           // GEN: [F][Dp] of the current example
-    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    float* Es = reinterpret_cast<float*>(lut + (GEN ? PP : 0));   // GEN: [F][Dp] of the current example
+    f32x4* red = reinterpret_cast<f32x4*>(Es + (GEN ? (a.F * (a.D + 1) + 7) / 4 * 4 : 0));   // HALVES == 2: [4][NT*NT][64], 16-byte aligned
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2;
+    const int r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
     const int slab = blockIdx.x;
     const int64_t nk = (a.Mtot + 3) / 4;                      // 4-row MFMA k-steps in total
@@ -889,42 +1053,66 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs a) {
         for (int i = 0; i < NT; ++i) { const uint32_t ij = lut[i * 16 + r]; fi[i] = (ij & 0xffff) * Dp; fj[i] = (ij >> 16) * Dp; }
     }
 
-    auto body = [&](int64_t ks, int64_t ke, int bcur) {       // k-steps [ks, ke); GEN: all inside example bcur
-        for (int64_t k0 = ks; k0 < ke; k0 += UNR) {
-            float av[UNR][NT], bv[UNR][NT];
+    auto load = [&](int64_t k0, int64_t ke, float (&av)[UNR][NT], float (&bv)[UNR][NT]) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int64_t m = 4 * (k0 + u) + kk;
-                const bool ok = (k0 + u < ke) && m < a.Mtot;
-                const int64_t mm = ok ? m : a.Mtot - 1;
-                const RowPos rp = row_pos(mm, a.lgSo);
-                const float* brow = a.dC + mm * PP + r;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t m = 4 * (k0 + u) + kk;
+            const bool ok = (k0 + u < ke) && m < a.Mtot;
+            const int64_t mm = ok ? m : a.Mtot - 1;
+            const RowPos rp = row_pos(mm, a.lgSo);
+            const float* brow = a.dC + mm * PP + r;
 #pragma unroll
-                for (int q = 0; q < NT; ++q) bv[u][q] = ok ? brow[16 * q] : 0.f;
-                if (GEN) {
-                    const int iy = 2 * rp.y + dh, jx = 2 * rp.x + dw;
+            for (int q = 0; q < NT; ++q) bv[u][q] = ok ? brow[16 * q] : 0.f;
+            if (GEN) {
+                const int iy = 2 * rp.y + dh, jx = 2 * rp.x + dw;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) av[u][i] = (i * 16 + r < P) ? Es[fi[i] + iy] * Es[fj[i] + jx] : 0.f;
-                } else {
-                    const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
+                for (int i = 0; i < NT; ++i) av[u][i] = (i * 16 + r < P) ? Es[fi[i] + iy] * Es[fj[i] + jx] : 0.f;
+            } else {
+                const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) av[u][i] = act_pos(arow[16 * i], a.act);
-                }
+                for (int i = 0; i < NT; ++i) av[u][i] = arow[16 * i];
             }
+        }
+    };
+    auto body = [&](int64_t ks, int64_t ke) {                 // k-steps [ks, ke); GEN: all inside one example
+        if (ks >= ke) return;
+        float av[UNR][NT], bv[UNR][NT], an[UNR][NT], bn[UNR][NT];
+        load(ks, ke, av, bv);
+        for (int64_t k0 = ks; k0 < ke; k0 += UNR) {
+            const bool more = k0 + UNR < ke;
+            if (more) load(k0 + UNR, ke, an, bn);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
 #pragma unroll
                 for (int q = 0; q < NT; ++q) bs[q] += bv[u][q];
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i) {
+                    const float x = GEN ? av[u][i] : act_pos(av[u][i], a.act);
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(av[u][i], bv[u][q], acc[i][q]);
+                    for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(x, bv[u][q], acc[i][q]);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) { av[u][i] = an[u][i]; bv[u][i] = bn[u][i]; }
             }
         }
     };
+    // this wave's share of [lo, hi): the lower or upper half (k-steps, rounded to UNR)
+    auto share = [&](int64_t lo, int64_t hi, int64_t* s0, int64_t* s1) {
+        if (HALVES == 1) { *s0 = lo; *s1 = hi; return; }
+        const int64_t mid = lo + ((hi - lo + 1) / 2 + UNR - 1) / UNR * UNR;
+        const int64_t m2 = mid < hi ? mid : hi;
+        *s0 = half == 0 ? lo : m2;
+        *s1 = half == 0 ? m2 : hi;
+    };
 
     if (!GEN) {
-        body(k_lo, k_hi, 0);
+        int64_t s0, s1;
+        share(k_lo, k_hi, &s0, &s1);
+        body(s0, s1);
     } else if (k_lo < k_hi) {
         const int S2 = So * So;
         const int64_t kpe = S2 / 4 > 0 ? S2 / 4 : 1;           // k-steps per example (S2 >= 4)
@@ -932,13 +1120,41 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs a) {
             const int b = (int)((4 * k0) >> (2 * a.lgSo));
             const int64_t kend = min(k_hi, ((int64_t)b + 1) * kpe);
             __syncthreads();
-            for (int e = tid; e < a.F * a.D; e += 256) {
+            for (int e = tid; e < a.F * a.D; e += NTH) {
                 const int f = e / a.D, d = e - f * a.D;
                 Es[f * Dp + d] = a.in[(int64_t)b * a.F * a.D + e];
             }
             __syncthreads();
-            body(k0, kend, b);
+            int64_t s0, s1;
+            share(k0, kend, &s0, &s1);
+            body(s0, s1);
             k0 = kend;
+        }
+    }
+    if (HALVES == 2) {                                         // upper half -> LDS -> added by the lower half
+        __syncthreads();
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) red[(tap * NT * NT + i * NT + q) * 64 + lane] = acc[i][q];
+        }
+        __syncthreads();
+        if (half == 1) {
+            if (tap == 0) {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) reinterpret_cast<float*>(red + 4 * NT * NT * 64)[q * 64 + lane] = bs[q];
+            }
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[i][q] += red[(tap * NT * NT + i * NT + q) * 64 + lane];
+        if (tap == 0) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bs[q] += reinterpret_cast<float*>(red + 4 * NT * NT * 64)[q * 64 + lane];
         }
     }
     // ---- write this slab -----------------------------------------------------------------------------------
@@ -1052,16 +1268,33 @@ static int launch_conv_fwd_taps(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int NT, int RM, bool L0>
+template <int NT, int RM, bool GEN>
+static int launch_conv_fwd_rows(const ConvArgs& a, hipStream_t st) {
+    constexpr int PP = NT * 16, BM = 64 * RM;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int n_ex = GEN ? (BM > S2 ? BM / S2 : 1) : 0;
+    const size_t lds = (size_t)4 * PP * (PP + 4) * 4 + (size_t)(GEN ? PP + n_ex * a.F * (a.D + 1) : 0) * 4 + 16;
+    int rc = set_lds(conv_fwd_rows_kernel<NT, RM, GEN>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_fwd_rows_kernel<NT, RM, GEN>), dim3((unsigned)((a.Mtot + BM - 1) / BM)), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT, int RM, bool L0, int HALVES>
 static int launch_dgrad_taps(const DgradArgs& a, hipStream_t st) {
     constexpr int PP = NT * 16, BM = 16 * RM;
     const int S2 = 1 << (2 * a.lgSo);
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
-    const size_t lds = (size_t)(L0 ? PP + 5 * n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F : 0) * 4 + 16;
-    int rc = set_lds(dgrad_taps_kernel<NT, RM, L0>, lds);
+    const int So = 1 << a.lgSo;
+    const bool fast = L0 && RM == 4 && a.lgSo >= 4 && a.lgSo <= 6;
+    const size_t scratch = fast ? (size_t)(4 + 4 * HALVES) * PP * So : (size_t)4 * HALVES * n_ex * a.F * (a.D + 1);
+    const size_t lds = (L0 ? (size_t)PP + n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F + scratch : 0) * 4 + 16;
+    int rc = set_lds(dgrad_taps_kernel<NT, RM, L0, HALVES>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((dgrad_taps_kernel<NT, RM, L0>), dim3((unsigned)((a.Mtot + rows_per_wg - 1) / rows_per_wg)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dgrad_taps_kernel<NT, RM, L0, HALVES>), dim3((unsigned)((a.Mtot + rows_per_wg - 1) / rows_per_wg)),
+                       dim3(256 * HALVES), lds, st, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1076,8 +1309,16 @@ static int launch_dgrad_taps(const DgradArgs& a, hipStream_t st) {
 
 template <int NT, bool GEN>
 static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
-    const size_t lds = (size_t)(GEN ? NT * 16 + a.F * (a.D + 1) : 0) * 4 + 16;
-    hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN>), dim3(nsl), dim3(256), lds, st, a);
+    const int64_t rows_per_slab = (a.Mtot + nsl - 1) / nsl;
+    const size_t base = (size_t)(GEN ? NT * 16 + (a.F * (a.D + 1) + 7) / 4 * 4 : 0) * 4 + 16;
+    if (rows_per_slab >= 128) {      // enough rows to give two wavefronts per SIMD something to do
+        const size_t lds = base + (size_t)4 * NT * NT * 64 * 16 + (size_t)NT * 64 * 4;
+        int rc = set_lds(wgrad_taps_kernel<NT, GEN, 2>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN, 2>), dim3(nsl), dim3(512), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN, 1>), dim3(nsl), dim3(256), base, st, a);
+    }
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1111,6 +1352,11 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop
         const int nt4 = g.Pp / 16;
         const int64_t wg16 = (a.Mtot + 15) / 16;
+        if (wg16 >= 4 * 512) {                    // many rows: whole filter in LDS, a wave runs all four taps
+            if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_rows<NT_, 1, true>(a, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_rows<NT_, 1, false>(a, st))); }
+            return rc;
+        }
         if (l == 0) {
             if (wg16 >= 4 * 1024) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 4, true>(a, st))); }
             else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_taps<NT_, 2, true>(a, st))); }
@@ -1181,9 +1427,13 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         if (g.Pp <= 64) {
             const int nt4 = g.Pp / 16;
             const int64_t wg16 = (a.Mtot + 15) / 16;
-            if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 4, true>(a, st))); }
-            else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 2, false>(a, st))); }
-            else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 1, false>(a, st))); }
+            if (l == 0) {
+                const int S2 = 1 << (2 * a.lgSo);
+                if (S2 >= 128) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 4, true, 2>(a, st))); }   // >= 2 m tiles
+                else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 4, true, 1>(a, st))); }
+            }
+            else if (wg16 >= 2 * 512) { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 2, false, 1>(a, st))); }
+            else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 1, false, 1>(a, st))); }
             return rc;
         }
         pick_nt(4 * g.Pp / 16, &nblk, &NT);
