@@ -428,7 +428,7 @@ struct WgradArgs {
 };
 
 template <int NT, bool GEN>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int BI = 64, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = WG_KM;
     constexpr int NB = KM * BQ / 256, NA = KM * BI / 4 / 256;     // per-thread B' floats / A' float4s per step
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         __syncthreads();
         if (st + 1 < s_hi) fetch(st + 1);                 // in flight while this step's MFMAs run
         // ---- MFMA over the KM rows ------------------------------------------------------------------
-#pragma unroll 4
+#pragma unroll 2
         for (int ks4 = 0; ks4 < KM; ks4 += 4) {
             float av;
             if (GEN) {
@@ -1018,24 +1018,27 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 }
 
 // wgrad_taps: wave t accumulates the [PP x PP] weight-gradient block of tap t over its share of the
-// workgroup's chunk of rows.  Both operands are dword fragment loads straight from L2 (A' = act(C_{l-1}) patch
-// channel, B' = dC row), or, for layer 0, A' is generated from the example's embedding tile in LDS.  A
-// workgroup has 4*HALVES wavefronts: with HALVES = 2 the chunk is cut in two and the two partial blocks of a
-// tap are added (lower half first) through LDS.  Loads of step i+1 are issued before the MFMAs of step i.
+// workgroup's chunk of rows.  The dC rows of a sub-chunk (<= WGT_SUB rows) are staged ONCE into LDS with
+// 16-byte loads and shared by all taps (B' fragments = conflict-free ds_read_b32: the row pitch PP = 16 mod 32
+// puts the two k rows of a half-wave on disjoint banks); A' = act(C_{l-1}) patch channels are dword fragment
+// loads from L2, or, for layer 0, generated from the embedding tiles held in LDS.  With HALVES = 2 the
+// sub-chunk is cut in two and the two partial blocks of a tap are added (lower half first) through LDS.
+#define WGT_SUB 256
 template <int NT, bool GEN, int HALVES>
 __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
     constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // GEN: [PP]
-    float* Es = reinterpret_cast<float*>(lut + (GEN ? PP : 0));   // GEN: [F][Dp] of the current example
-    f32x4* red = reinterpret_cast<f32x4*>(Es + (GEN ? (a.F * (a.D + 1) + 7) / 4 * 4 : 0));   // HALVES == 2: [4][NT*NT][64], 16-byte aligned
+    float* Bs = reinterpret_cast<float*>(smem);               // [WGT_SUB][PP]
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Bs + WGT_SUB * PP);   // GEN: [PP]
+    float* Es = reinterpret_cast<float*>(lut + (GEN ? PP : 0));       // GEN: [n_ex][F][Dp] of the sub-chunk's examples
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2;
     const int r = lane & 15, kk = lane >> 4;
-    const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
+    const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
+    const int n_ex_max = GEN ? WGT_SUB / S2 + 2 : 0;
+    f32x4* red = reinterpret_cast<f32x4*>(Es + (GEN ? (n_ex_max * a.F * Dp + 7) / 4 * 4 : 0));   // HALVES == 2
     const int slab = blockIdx.x;
-    const int64_t nk = (a.Mtot + 3) / 4;                      // 4-row MFMA k-steps in total
-    const int64_t cps = (nk + gridDim.x - 1) / gridDim.x;
-    const int64_t k_lo = slab * cps, k_hi = min(nk, k_lo + cps);
+    const int64_t rows_per_slab = ((a.Mtot + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+    const int64_t m_lo = slab * rows_per_slab, m_hi = min(a.Mtot, m_lo + rows_per_slab);
 
     f32x4 acc[NT][NT];
 #pragma unroll
@@ -1053,82 +1056,79 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
         for (int i = 0; i < NT; ++i) { const uint32_t ij = lut[i * 16 + r]; fi[i] = (ij & 0xffff) * Dp; fj[i] = (ij >> 16) * Dp; }
     }
 
-    auto load = [&](int64_t k0, int64_t ke, float (&av)[UNR][NT], float (&bv)[UNR][NT]) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t m = 4 * (k0 + u) + kk;
-            const bool ok = (k0 + u < ke) && m < a.Mtot;
-            const int64_t mm = ok ? m : a.Mtot - 1;
-            const RowPos rp = row_pos(mm, a.lgSo);
-            const float* brow = a.dC + mm * PP + r;
-#pragma unroll
-            for (int q = 0; q < NT; ++q) bv[u][q] = ok ? brow[16 * q] : 0.f;
-            if (GEN) {
-                const int iy = 2 * rp.y + dh, jx = 2 * rp.x + dw;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) av[u][i] = (i * 16 + r < P) ? Es[fi[i] + iy] * Es[fj[i] + jx] : 0.f;
-            } else {
-                const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) av[u][i] = arow[16 * i];
-            }
+    for (int64_t ms = m_lo; ms < m_hi; ms += WGT_SUB) {       // sub-chunks of the slab's rows
+        const int nrow = (int)min((int64_t)WGT_SUB, m_hi - ms);
+        const int b_lo = (int)(ms >> (2 * a.lgSo));
+        __syncthreads();                                       // previous sub-chunk fully consumed
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.dC + ms * PP);
+            for (int e = tid; e < nrow * (PP / 4); e += NTH) reinterpret_cast<float4*>(Bs)[e] = src[e];
+            for (int e = nrow * (PP / 4) + tid; e < ((nrow + 3) / 4 * 4) * (PP / 4); e += NTH)
+                reinterpret_cast<float4*>(Bs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);     // pad to a whole k-step
         }
-    };
-    auto body = [&](int64_t ks, int64_t ke) {                 // k-steps [ks, ke); GEN: all inside one example
-        if (ks >= ke) return;
-        float av[UNR][NT], bv[UNR][NT], an[UNR][NT], bn[UNR][NT];
-        load(ks, ke, av, bv);
-        for (int64_t k0 = ks; k0 < ke; k0 += UNR) {
-            const bool more = k0 + UNR < ke;
-            if (more) load(k0 + UNR, ke, an, bn);
+        if (GEN) {
+            const int b_hi = (int)((ms + nrow - 1) >> (2 * a.lgSo));
+            stage_examples(Es, a.in, b_lo, b_hi - b_lo + 1, a.B, a.F, a.D, Dp);
+        }
+        __syncthreads();
+        // this wave's k-steps (4 rows each) of the sub-chunk
+        const int nk = (nrow + 3) / 4;
+        int k0 = 0, k1 = nk;
+        if (HALVES == 2) {
+            const int mid = min(nk, ((nk + 1) / 2 + UNR - 1) / UNR * UNR);
+            k0 = half == 0 ? 0 : mid;
+            k1 = half == 0 ? mid : nk;
+        }
+        auto load_a = [&](int k, float (&av)[UNR][NT]) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
+                const int row = 4 * (k + u) + kk;
+                int64_t m = ms + row;
+                if (k + u >= k1 || m >= a.Mtot) m = a.Mtot - 1;     // B' is zero there, any finite A' will do
+                const RowPos rp = row_pos(m, a.lgSo);
+                if (GEN) {
+                    const int eb = (rp.b - b_lo) * a.F * Dp, iy = eb + 2 * rp.y + dh, jx = eb + 2 * rp.x + dw;
 #pragma unroll
-                for (int q = 0; q < NT; ++q) bs[q] += bv[u][q];
+                    for (int i = 0; i < NT; ++i) av[u][i] = (i * 16 + r < P) ? Es[fi[i] + iy] * Es[fj[i] + jx] : 0.f;
+                } else {
+                    const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const float x = GEN ? av[u][i] : act_pos(av[u][i], a.act);
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(x, bv[u][q], acc[i][q]);
+                    for (int i = 0; i < NT; ++i) av[u][i] = arow[16 * i];
                 }
             }
-            if (more) {
+        };
+        if (k0 < k1) {
+            float av[UNR][NT], an[UNR][NT];
+            load_a(k0, av);
+            for (int k = k0; k < k1; k += UNR) {
+                const bool more = k + UNR < k1;
+                if (more && !GEN) load_a(k + UNR, an);              // global A' of the next step in flight
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
+                for (int u = 0; u < UNR; ++u) {
+                    if (k + u < k1) {
+                        float bv[NT];
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) { av[u][i] = an[u][i]; bv[u][i] = bn[u][i]; }
+                        for (int q = 0; q < NT; ++q) bv[q] = Bs[(4 * (k + u) + kk) * PP + q * 16 + r];
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) bs[q] += bv[q];
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) {
+                            const float x = GEN ? av[u][i] : act_pos(av[u][i], a.act);
+#pragma unroll
+                            for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(x, bv[q], acc[i][q]);
+                        }
+                    }
+                }
+                if (more) {
+                    if (GEN) load_a(k + UNR, av);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                            for (int i = 0; i < NT; ++i) av[u][i] = an[u][i];
+                    }
+                }
             }
-        }
-    };
-    // this wave's share of [lo, hi): the lower or upper half (k-steps, rounded to UNR)
-    auto share = [&](int64_t lo, int64_t hi, int64_t* s0, int64_t* s1) {
-        if (HALVES == 1) { *s0 = lo; *s1 = hi; return; }
-        const int64_t mid = lo + ((hi - lo + 1) / 2 + UNR - 1) / UNR * UNR;
-        const int64_t m2 = mid < hi ? mid : hi;
-        *s0 = half == 0 ? lo : m2;
-        *s1 = half == 0 ? m2 : hi;
-    };
-
-    if (!GEN) {
-        int64_t s0, s1;
-        share(k_lo, k_hi, &s0, &s1);
-        body(s0, s1);
-    } else if (k_lo < k_hi) {
-        const int S2 = So * So;
-        const int64_t kpe = S2 / 4 > 0 ? S2 / 4 : 1;           // k-steps per example (S2 >= 4)
-        for (int64_t k0 = k_lo; k0 < k_hi;) {
-            const int b = (int)((4 * k0) >> (2 * a.lgSo));
-            const int64_t kend = min(k_hi, ((int64_t)b + 1) * kpe);
-            __syncthreads();
-            for (int e = tid; e < a.F * a.D; e += NTH) {
-                const int f = e / a.D, d = e - f * a.D;
-                Es[f * Dp + d] = a.in[(int64_t)b * a.F * a.D + e];
-            }
-            __syncthreads();
-            int64_t s0, s1;
-            share(k0, kend, &s0, &s1);
-            body(s0, s1);
-            k0 = kend;
         }
     }
     if (HALVES == 2) {                                         // upper half -> LDS -> added by the lower half
@@ -1138,9 +1138,6 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int q = 0; q < NT; ++q) red[(tap * NT * NT + i * NT + q) * 64 + lane] = acc[i][q];
-        }
-        __syncthreads();
-        if (half == 1) {
             if (tap == 0) {
 #pragma unroll
                 for (int q = 0; q < NT; ++q) reinterpret_cast<float*>(red + 4 * NT * NT * 64)[q * 64 + lane] = bs[q];
@@ -1310,13 +1307,17 @@ static int launch_dgrad_taps(const DgradArgs& a, hipStream_t st) {
 template <int NT, bool GEN>
 static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
     const int64_t rows_per_slab = (a.Mtot + nsl - 1) / nsl;
-    const size_t base = (size_t)(GEN ? NT * 16 + (a.F * (a.D + 1) + 7) / 4 * 4 : 0) * 4 + 16;
+    const int S2 = 1 << (2 * a.lgSo);
+    const int n_ex_max = GEN ? WGT_SUB / S2 + 2 : 0;
+    const size_t base = (size_t)(WGT_SUB * NT * 16 + (GEN ? NT * 16 + (n_ex_max * a.F * (a.D + 1) + 7) / 4 * 4 : 0)) * 4 + 16;
     if (rows_per_slab >= 128) {      // enough rows to give two wavefronts per SIMD something to do
         const size_t lds = base + (size_t)4 * NT * NT * 64 * 16 + (size_t)NT * 64 * 4;
         int rc = set_lds(wgrad_taps_kernel<NT, GEN, 2>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN, 2>), dim3(nsl), dim3(512), lds, st, a);
     } else {
+        int rc = set_lds(wgrad_taps_kernel<NT, GEN, 1>, base);
+        if (rc) return rc;
         hipLaunchKernelGGL((wgrad_taps_kernel<NT, GEN, 1>), dim3(nsl), dim3(256), base, st, a);
     }
     CFFM_CHECK_LAUNCH();

@@ -274,3 +274,43 @@ def test_gather_edge_cases():
     # batch of 1 through the whole forward (the reference's tf.squeeze breaks at B == 1, quirk Q10)
     out_ref, _ = orc.forward(to64(p32), X[:1], cfg)
     close(eng.predict(torch.from_numpy(X[:1]).cuda()).cpu().numpy(), out_ref, 'predict B=1')
+
+
+# ---- BASELINE.json configs at their full sizes (size-independent properties) -----------------------------
+FULL = {
+    'ml-tag (cfg1 shape)': dict(M=90445, F=3, K=32, D=32, B=1024, act='elu'),
+    'book-crossing (cfg3)': dict(M=226336, F=6, K=32, D=32, B=512, act='relu'),
+    'synthetic 1M, 32 fields, dim 64, batch 8192 (cfg4)': dict(M=1000000, F=32, K=64, D=64, B=8192, act='relu'),
+}
+
+
+@pytest.mark.parametrize('name', list(FULL))
+def test_full_size_configs(name):
+    """At full size the oracle cannot materialise the batch (66.6 GB outer map at cfg4), so use what the domain
+    offers: examples are independent in the forward pass (any few rows must match the oracle run on just those
+    rows), a train step must leave every table row outside the batch bit-identical and its accumulator at
+    1e-8, touched rows must all move, and the loss must be finite."""
+    from cffm_amd import synth
+    c = FULL[name]
+    cfg = CFFMConfig(M=c['M'], F=c['F'], K=c['K'], D=c['D'], activation=c['act'])
+    p32 = init_params(cfg, seed=5)
+    eng = engine_for(cfg, p32)
+    X, y = synth.batches(cfg.M, cfg.F, c['B'], 1, seed=9)
+    ids, yt = torch.from_numpy(X[0]).cuda(), torch.from_numpy(y[0]).cuda()
+    out = eng.predict(ids).cpu().numpy()
+    rows = [0, 1, c['B'] // 2, c['B'] - 1]
+    ref, _ = orc.forward(to64(p32), X[0][rows], cfg)
+    close(out[rows], ref, 'predict rows of ' + name)
+    assert np.isfinite(out).all()
+    before_inner = eng.inner.clone()
+    loss = float(eng.train_step(ids, yt).cpu()[0])
+    torch.cuda.synchronize()
+    assert np.isfinite(loss) and loss > 0
+    L0 = np.sqrt(np.mean((y[0].astype(np.float64) - out) ** 2) + 1e-10)
+    assert abs(loss - L0) <= 1e-4 * max(1.0, L0)                 # the loss is that of the pre-update forward
+    touched = torch.zeros(cfg.M, dtype=torch.bool, device='cuda')
+    touched[ids.reshape(-1).long()] = True
+    assert torch.equal(eng.inner[~touched], before_inner[~touched])
+    assert bool((eng.inner_acc[~touched] == 1e-8).all()) and bool((eng.inner_acc[touched] > 1e-8).any(dim=1).all())
+    assert bool((eng.outer_acc[~touched] == 1e-8).all()) and bool((eng.fbias_acc[~touched] == 1e-8).all())
+    assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
