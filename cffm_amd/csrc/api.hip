@@ -100,11 +100,16 @@ static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const f
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
     const Geo g = make_geo(s);
-    rc = cffm_gather_impl(s, tab, ids, B, s->inner_conv ? (float*)(w + wl.Ei) : nullptr,
-                          s->outer_conv ? (float*)(w + wl.Eo) : nullptr, (float*)(w + wl.fb),
-                          fused_step ? (unsigned long long*)(w + wl.sort_keys) : nullptr, stream);
-    if (rc) return rc;
-    if ((rc = cffm_inner_fwd(s, theta, ws, B, stream))) return rc;
+    if (fused_step && s->inner_conv && s->outer_conv) {
+        // the inner-branch kernel gathers the rows of its example itself (one launch less)
+        if ((rc = cffm_inner_fwd_impl(s, theta, ws, B, tab, ids, stream))) return rc;
+    } else {
+        rc = cffm_gather_impl(s, tab, ids, B, s->inner_conv ? (float*)(w + wl.Ei) : nullptr,
+                              s->outer_conv ? (float*)(w + wl.Eo) : nullptr, (float*)(w + wl.fb),
+                              fused_step ? (unsigned long long*)(w + wl.sort_keys) : nullptr, stream);
+        if (rc) return rc;
+        if ((rc = cffm_inner_fwd(s, theta, ws, B, stream))) return rc;
+    }
     if (s->outer_conv) {
         if ((rc = cffm_outer_conv0_fwd(s, theta, ws, B, stream))) return rc;
         for (int l = 1; l < g.live; ++l)

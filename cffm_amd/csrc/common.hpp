@@ -135,15 +135,32 @@ __device__ __forceinline__ float act_relu_grad(float c, int act) {
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------
+// 64-lane reductions on the DPP path (v_add_f32 ... row_shr / row_bcast): ~6 VALU ops, against six dependent
+// ds_bpermute round trips (~60 cycles each) for the __shfl_xor butterfly.  Lane 63 ends up with the total,
+// which v_readlane broadcasts as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v, float identity) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1, 0xf>(v, 0.f);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v, 0.f);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v, 0.f);    // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v, 0.f);    // row_mirror          -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xa>(v, 0.f);    // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v, 0.f);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    const float ninf = -INFINITY;
+    v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_mov<0x141, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_mov<0x140, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(v, ninf));
+    v = fmaxf(v, dpp_mov<0x143, 0xc>(v, ninf));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Block-wide sum in a fixed order (bitwise reproducible); red must hold >= blockDim/64 floats.

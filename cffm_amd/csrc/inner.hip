@@ -5,7 +5,7 @@
 // Everything is element-wise followed by ONE dot product, so the whole branch is a single pass over
 // the gathered rows held in LDS with a wavefront/block reduction at the end: nothing of the
 // [B,P,K/2,2] intermediate (1 GB at F=32,K=64,B=8192) is ever written.
-#include "common.hpp"
+#include "internal.hpp"
 
 struct InnerUnit {
     float x0, x1, I0, I1, z0, z1, s0, s1, eix, eiy, ejx, ejy;
@@ -30,18 +30,55 @@ __device__ __forceinline__ InnerUnit inner_unit(const float* E, const uint32_t* 
     return u;
 }
 
+// Fused-step variant (fg.ids != NULL): this kernel IS the embedding gather.  The workgroup of example b
+// fetches its F rows of all three tables straight from HBM (16-byte pieces, row pieces of one slot on
+// consecutive lanes), keeps the inner rows in LDS for its own use, and leaves Ei/Eo/fb (and the packed sort keys
+// of the sparse update) in the workspace for the later stages - one launch and one pass less than a separate gather.
+struct FusedGather {
+    const int32_t* ids;                    // NULL: the rows were gathered by cffm_gather already
+    const float *inner, *outer, *fbias;
+    float *Ei, *Eo, *fb;
+    unsigned long long* keys;
+    int M, D;
+};
+
 __global__ __launch_bounds__(256) void inner_fwd_kernel(Geo g, const float* __restrict__ Ei,
                                                         const float* __restrict__ cw_g, const float* __restrict__ cb_g,
                                                         const float* __restrict__ wd, const float* __restrict__ bd,
-                                                        float* __restrict__ inner_out) {
+                                                        float* __restrict__ inner_out, FusedGather fg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* E = reinterpret_cast<float*>(smem);                                   // [F*K]
     uint32_t* lut = reinterpret_cast<uint32_t*>(E + g.F * g.K);                 // [Pp]
     float* red = reinterpret_cast<float*>(lut + g.Pp);                          // [4]
     const int b = blockIdx.x;
     const int FK4 = g.F * g.K / 4;
-    const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * g.F * g.K);
-    for (int i = threadIdx.x; i < FK4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
+    if (fg.ids != nullptr) {
+        const int K4 = g.K / 4, D4 = fg.D / 4;
+        const int32_t* idb = fg.ids + (int64_t)b * g.F;
+        for (int i = threadIdx.x; i < g.F * (K4 + D4); i += blockDim.x) {
+            const bool in = i < g.F * K4;
+            const int j = in ? i : i - g.F * K4, per = in ? K4 : D4, f = j / per, c = j - f * per;
+            int id = idb[f];
+            id = id < 0 ? 0 : (id >= fg.M ? fg.M - 1 : id);
+            const float4 v = reinterpret_cast<const float4*>(in ? fg.inner : fg.outer)[(int64_t)id * per + c];
+            if (in) {
+                reinterpret_cast<float4*>(E)[j] = v;
+                reinterpret_cast<float4*>(fg.Ei + (int64_t)b * g.F * g.K)[j] = v;
+            } else {
+                reinterpret_cast<float4*>(fg.Eo + (int64_t)b * g.F * fg.D)[j] = v;
+            }
+        }
+        if (threadIdx.x < g.F) {
+            const int raw = idb[threadIdx.x];
+            const int id = raw < 0 ? 0 : (raw >= fg.M ? fg.M - 1 : raw);
+            const int64_t slot = (int64_t)b * g.F + threadIdx.x;
+            fg.fb[slot] = fg.fbias[id];
+            fg.keys[slot] = ((unsigned long long)(unsigned)raw << 32) | (unsigned long long)slot;
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * g.F * g.K);
+        for (int i = threadIdx.x; i < FK4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
+    }
     build_pair_lut(lut, g.F, g.Pp);
     float cw[4] = {cw_g[0], cw_g[1], cw_g[2], cw_g[3]};
     float cb[2] = {cb_g[0], cb_g[1]};
@@ -143,6 +180,11 @@ __global__ __launch_bounds__(256) void inner_bwd_kernel(Geo g, int B, const floa
 }
 
 extern "C" int cffm_inner_fwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {
+    return cffm_inner_fwd_impl(s, theta, ws, B, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int cffm_inner_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const cffm_tables_t* tab,
+                        const int32_t* ids, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0 || !s->inner_conv) return 0;
@@ -151,9 +193,17 @@ extern "C" int cffm_inner_fwd(const cffm_shape_t* s, const float* theta, void* w
     const Geo g = make_geo(s);
     char* w = (char*)ws;
     const size_t lds = (size_t)(g.F * g.K + g.Pp + 8) * 4;
+    FusedGather fg;
+    fg.ids = tab ? ids : nullptr;
+    if (tab) {
+        fg.inner = tab->inner_emb; fg.outer = tab->outer_emb; fg.fbias = tab->feat_bias;
+        fg.Ei = (float*)(w + wl.Ei); fg.Eo = (float*)(w + wl.Eo); fg.fb = (float*)(w + wl.fb);
+        fg.keys = (unsigned long long*)(w + wl.sort_keys);
+        fg.M = s->M; fg.D = s->D;
+    }
     hipLaunchKernelGGL(inner_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, g,
                        (const float*)(w + wl.Ei), theta + tl.inner_cw, theta + tl.inner_cb,
-                       theta + tl.inner_dw, theta + tl.inner_db, (float*)(w + wl.inner_out));
+                       theta + tl.inner_dw, theta + tl.inner_db, (float*)(w + wl.inner_out), fg);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

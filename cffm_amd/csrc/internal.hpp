@@ -16,3 +16,7 @@ int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* gr
 int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
                              const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo, const float* dfb,
                              void* ws, int32_t B_ws, bool prepacked, hipStream_t st);
+// tab != nullptr: fused step - the kernel gathers the rows of example b itself (all three tables) and leaves
+// Ei/Eo/fb and the packed sort keys in the workspace, so no separate gather launch is needed
+int cffm_inner_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const cffm_tables_t* tab,
+                        const int32_t* ids, hipStream_t st);
