@@ -192,7 +192,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(eng.loss_value(B)[0].item()) if world > 1 else float(eng.loss_buf[0].item())
+    loss = float(eng.loss_buf[0].item())
     if not np.isfinite(loss):
         raise SystemExit('bench.py: loss is not finite')
 

@@ -138,7 +138,8 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
 
 // backward through the slab reduction; fused = single-GPU step (local loss sum, Adagrad folded into the reduction)
 static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
-                         int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream) {
+                         int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream,
+                         bool unscaled = false) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -150,7 +151,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
         hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)wl.gpart_floats * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
-    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused, loss_out, stream))) return rc;
+    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused, loss_out, stream, unscaled))) return rc;
     if (s->outer_conv) {
         for (int l = g.live - 1; l >= 1; --l)
             if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
@@ -164,6 +165,23 @@ extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const fl
                              void* ws, float* grad, void* stream) {
     return backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr,
                          (hipStream_t)stream);
+}
+
+// Data-parallel backward: dL/dout = (out - y) / B_global WITHOUT the 1/L of the RMSE-style loss; grad must have room
+// for theta.n + 4 floats - element theta.n receives this rank's loss-term sum so that ONE all-reduce carries both.
+// cffm_dp_apply then applies 1/L to the summed gradients.  The packed rows for the all-gather are written to `rows`
+// [B*F][1 + K + D + 1] = (id bits | dEi | dEo | dfb).
+extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta, const int32_t* ids, const float* y,
+                                      int32_t B, int64_t B_global, void* ws, float* grad, float* rows, void* stream) {
+    int rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr,
+                           (hipStream_t)stream, true);
+    if (rc || B <= 0) return rc;
+    if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
+    cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
+    char* w = (char*)ws;
+    return cffm_pack_rows(s, ids, B, (const float*)(w + wl.dEi), (const float*)(w + wl.dEo), (const float*)(w + wl.dfb),
+                          (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }
 
 extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,

@@ -19,7 +19,7 @@
 // uses the same k permutation, which the contraction does not care about.
 // Channels are padded to Pp = ceil16(P) in every activation tensor so that 16-byte pieces never
 // straddle a row and tiles never straddle a filter tap; padded channels hold zeros.
-#include "common.hpp"
+#include "internal.hpp"
 
 #define KSTEP 32
 #define WG_KM 64       // rows of the M (reduction) dimension staged per wgrad step
@@ -869,6 +869,24 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 #pragma unroll
             for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(a.dC + m * PP + 16 * h + 4 * kk);
         }
+        // !L0: the mask operand C_{l-1} and the pool gradient do not depend on the MFMAs - fetch them now so that
+        // their latency hides behind the matrix work instead of sitting in the epilogue
+        float cpre[L0 ? 1 : RM][L0 ? 1 : NT][4], dpre[L0 ? 1 : RM][4];
+        int64_t ppos[L0 ? 1 : RM][4];
+        if (!L0) {
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int64_t m = m0 + rm * 16 + kk * 4 + j;
+                    if (m >= a.Mtot) m = a.Mtot - 1;
+                    const RowPos rp = row_pos(m, a.lgSo);
+                    ppos[rm][j] = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
+                    dpre[rm][j] = a.dt1[(int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y + dh];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cpre[rm][nt][j] = a.Cprev[ppos[rm][j] + nt * 16];
+                }
+        }
         f32x4 acc[RM][NT];
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm)
@@ -901,12 +919,9 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
                 if (!L0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int64_t m = mrow + j;
-                        if (m < a.Mtot) {
-                            const RowPos rp = row_pos(m, a.lgSo);
-                            const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + p;
-                            const float g = acc[rm][nt][j] + a.dt1[(int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y + dh];
-                            a.dprev[pos] = g * act_relu_grad(a.Cprev[pos], a.act);
+                        if (mrow + j < a.Mtot) {
+                            const float g = acc[rm][nt][j] + dpre[L0 ? 0 : rm][j];
+                            a.dprev[ppos[L0 ? 0 : rm][j] + nt * 16] = g * act_relu_grad(cpre[L0 ? 0 : rm][L0 ? 0 : nt][j], a.act);
                         }
                     }
                 } else {
@@ -1381,7 +1396,9 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     return rc;
 }
 
-static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st) {
+// which: bit 0 = weight/bias gradient, bit 1 = input gradient (the two only share their inputs, so the fused
+// step runs them on different streams)
+static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st, int which = 3) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -1392,7 +1409,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     make_slab_plan(s, B, tl, &sp);
     const SlabRange& sr = sp.r[sp.conv0 + l];
     int rc = 0;
-    {   // weight / bias gradient
+    if (which & 1) {   // weight / bias gradient
         WgradArgs a;
         a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dC = (const float*)(w + wl.dC[l]);
@@ -1414,7 +1431,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         if (rc) return rc;
         }
     }
-    {   // input gradient
+    if (which & 2) {   // input gradient
         DgradArgs a;
         a.dC = (const float*)(w + wl.dC[l]);
         a.W = theta + tl.conv_w[l];
@@ -1448,6 +1465,11 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         }
     }
     return rc;
+}
+
+int cffm_conv_bwd_part(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, int which,
+                       hipStream_t st) {
+    return conv_bwd_any(s, theta, ws, B, layer, st, which);
 }
 
 extern "C" int cffm_outer_conv0_fwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {

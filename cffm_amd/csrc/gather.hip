@@ -87,3 +87,34 @@ int cffm_gather_impl(const cffm_shape_t* s, const cffm_tables_t* t, const int32_
     CFFM_CHECK_LAUNCH();
     return 0;
 }
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const int32_t* __restrict__ ids, int64_t n_slots, int K, int D,
+                                                        const float* __restrict__ dEi, const float* __restrict__ dEo,
+                                                        const float* __restrict__ dfb, const float* __restrict__ scalars,
+                                                        float* __restrict__ sum_dst, float* __restrict__ rows) {
+    const int W = 1 + K + D + 1;
+    const int64_t total = n_slots * W;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sum_dst[0] = scalars[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t slot = i / W;
+        const int c = (int)(i - slot * W);
+        float v;
+        if (c == 0) v = __int_as_float(ids[slot]);
+        else if (c <= K) v = dEi[slot * K + (c - 1)];
+        else if (c <= K + D) v = dEo[slot * D + (c - 1 - K)];
+        else v = dfb[slot];
+        rows[i] = v;
+    }
+}
+
+int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const float* dEi, const float* dEo, const float* dfb,
+                   const float* scalars, float* sum_dst, float* rows, hipStream_t st) {
+    const int64_t n_slots = (int64_t)B * s->F;
+    const int64_t total = n_slots * (1 + s->K + s->D + 1);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, ids, n_slots, s->K, s->D, dEi, dEo, dfb, scalars,
+                       sum_dst, rows);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

@@ -197,6 +197,7 @@ struct HeadBwdArgs {
     int64_t stride_front, stride_back;    // slab strides of the head-front (att_W, att_b, bias) and head-back ranges
     int64_t front_len, back_len;
     int loss, outer_conv;
+    int unscaled;            // 1: leave the 1/L of the RMSE-style loss out of dout (data-parallel late scaling)
 };
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
@@ -212,8 +213,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     for (int64_t e = tid; e < a.front_len; e += 256) s_attW[e] = 0.f;        // att_W is the first member of the range
     for (int64_t e = tid; e < a.back_len; e += 256) s_d1w[e] = 0.f;          // d1_w is the first member of the range
     __syncthreads();
-    float sum;
-    if (a.sqerr) {           // same fixed-order sum in every workgroup
+    float sum = 0.f;
+    if (a.unscaled) {
+        sum = 0.f;           // not known yet: the caller all-reduces it together with the gradients
+    } else if (a.sqerr) {    // same fixed-order sum in every workgroup
         float part = 0.f;
         for (int i = tid; i < a.B; i += 256) part += a.sqerr[i];
         sum = block_sum(part, red);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     }
     const float invB = 1.f / (float)a.Bg;
     float L;
-    if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
+    if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = a.unscaled ? 1.f : sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
     else L = sum * invB;
     if (blockIdx.x == 0 && tid == 0) {
         a.scalars[1] = L;
@@ -361,7 +364,7 @@ extern "C" int cffm_head_bwd(const cffm_shape_t* s, const float* theta, void* ws
 }
 
 int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
-                       bool local_sum, float* loss_out, hipStream_t stream) {
+                       bool local_sum, float* loss_out, hipStream_t stream, bool unscaled) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -390,7 +393,7 @@ int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     a.s_d1w = gb + tl.d1_w; a.s_d1b = gb + tl.d1_b; a.s_d2w = gb + tl.d2_w; a.s_d2b = gb + tl.d2_b;
     a.s_linw = gb + tl.lin_w; a.s_linb = gb + tl.lin_b;
     a.stride_front = rf.len; a.stride_back = rb.len; a.front_len = rf.len; a.back_len = rb.len;
-    a.loss = s->loss; a.outer_conv = s->outer_conv;
+    a.loss = s->loss; a.outer_conv = s->outer_conv; a.unscaled = unscaled ? 1 : 0;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(CFFM_NSLAB_SMALL), dim3(256), 0, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     return 0;

@@ -9,7 +9,7 @@ int cffm_gather_impl(const cffm_shape_t* s, const cffm_tables_t* t, const int32_
 int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum,
                        hipStream_t st);
 int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
-                       bool local_sum, float* loss_out, hipStream_t st);
+                       bool local_sum, float* loss_out, hipStream_t st, bool unscaled = false);
 // theta != nullptr: the dense Adagrad update is fused into the slab reduction
 int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* grad, float* theta, float* acc, float lr,
                            hipStream_t st);
@@ -20,3 +20,19 @@ int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, co
 // Ei/Eo/fb and the packed sort keys in the workspace, so no separate gather launch is needed
 int cffm_inner_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const cffm_tables_t* tab,
                         const int32_t* ids, hipStream_t st);
+// one half of a conv layer's backward: which & 1 = weight/bias gradient, which & 2 = input gradient
+int cffm_conv_bwd_part(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, int which,
+                       hipStream_t st);
+// the two halves of the sparse update: stable sort of the packed keys, then the segment-sum + Adagrad sweep
+int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_rows, void* ws, int32_t B_ws, bool prepacked,
+                        hipStream_t st, int64_t id_stride = 1);
+struct LateScale;
+int cffm_sparse_apply_strided(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
+                              const float* dEi, int64_t sEi, const float* dEo, int64_t sEo, const float* dfb, int64_t sfb,
+                              void* ws, int32_t B_ws, LateScale ls, hipStream_t st);
+int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
+                           const float* dEi, const float* dEo, const float* dfb, void* ws, int32_t B_ws, hipStream_t st);
+// rows[slot] = (id bits | dEi | dEo | dfb) for the all-gather of the data-parallel step; also copies the local
+// loss-term sum (scalars[0]) to *sum_dst
+int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const float* dEi, const float* dEo, const float* dfb,
+                   const float* scalars, float* sum_dst, float* rows, hipStream_t st);

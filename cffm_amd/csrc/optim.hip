@@ -32,19 +32,31 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+// Late loss normalisation of the data-parallel step: the backward pass ran with dL/dout = (out - y) / Bg, i.e.
+// WITHOUT the 1/L of the RMSE-style loss (CFFM.py:493), because L needs the loss-term sum over the GLOBAL batch,
+// which only exists after the all-reduce that also carries the gradients.  Every gradient is linear in dL/dout,
+// so the factor 1/L = rsqrt(sum / Bg + 1e-10) is applied here, on the summed gradient.
+struct LateScale { const float* sum; float inv_Bg; int on; };
+__device__ __forceinline__ float late_scale(const LateScale& ls) {
+    return ls.on ? 1.f / sqrtf(ls.sum[0] * ls.inv_Bg + 1e-10f) : 1.f;
+}
+
 __global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ v, float* __restrict__ acc,
-                                                            const float* __restrict__ grad, int64_t n, float lr) {
+                                                            const float* __restrict__ grad, int64_t n, float lr,
+                                                            LateScale ls, float* __restrict__ loss_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && loss_out != nullptr) loss_out[0] = ls.on ? sqrtf(ls.sum[0] * ls.inv_Bg + 1e-10f) : ls.sum[0] * ls.inv_Bg;
     if (i >= n) return;
-    const float g = grad[i];
+    const float g = grad[i] * late_scale(ls);
     const float a = acc[i] + g * g;
     acc[i] = a;
     v[i] -= lr * g / sqrtf(a);
 }
 
-__global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restrict__ ids, unsigned long long* keys, int64_t n) {
+__global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restrict__ ids, unsigned long long* keys, int64_t n,
+                                                        int64_t id_stride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = ((unsigned long long)(unsigned)ids[i] << 32) | (unsigned long long)i;
+    if (i < n) keys[i] = ((unsigned long long)(unsigned)ids[i * id_stride] << 32) | (unsigned long long)i;
 }
 
 // one wavefront per sorted position; only segment heads do work
@@ -52,7 +64,9 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
     const unsigned long long* __restrict__ keys, int64_t n, int M, int K, int D,
     const float* __restrict__ dEi, const float* __restrict__ dEo, const float* __restrict__ dfb,
     float* __restrict__ inner, float* __restrict__ outer, float* __restrict__ fbias,
-    float* __restrict__ a_inner, float* __restrict__ a_outer, float* __restrict__ a_fbias, float lr) {
+    float* __restrict__ a_inner, float* __restrict__ a_outer, float* __restrict__ a_fbias, float lr,
+    int64_t sEi, int64_t sEo, int64_t sfb, LateScale ls) {
+    const float gscale = late_scale(ls);
     const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pos >= n) return;
@@ -69,8 +83,9 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
                 const unsigned long long kq = keys[q];
                 if ((int)(kq >> 32) != id) break;
                 const int64_t sl = (int64_t)(kq & 0xffffffffull);
-                g += c < Ki ? dEi[sl * K + c] : (c < W - 1 ? dEo[sl * D + (c - Ki)] : dfb[sl]);
+                g += c < Ki ? dEi[sl * sEi + c] : (c < W - 1 ? dEo[sl * sEo + (c - Ki)] : dfb[sl * sfb]);
             }
+            g *= gscale;
             float *vp, *ap;
             if (c < Ki) { vp = inner + (int64_t)id * K + c; ap = a_inner + (int64_t)id * K + c; }
             else if (c < W - 1) { vp = outer + (int64_t)id * D + (c - Ki); ap = a_outer + (int64_t)id * D + (c - Ki); }
@@ -103,8 +118,9 @@ int cffm_reduce_slabs_impl(const cffm_shape_t* s, void* ws, int32_t B, float* gr
 
 extern "C" int cffm_dense_adagrad(float* theta, float* acc, const float* grad, int64_t n, float lr, void* stream) {
     if (n <= 0) return 0;
+    LateScale ls = {nullptr, 0.f, 0};
     hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       theta, acc, grad, n, lr);
+                       theta, acc, grad, n, lr, ls, (float*)nullptr);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -118,6 +134,13 @@ extern "C" int cffm_sparse_adagrad(const cffm_shape_t* s, const cffm_tables_t* t
 int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc,
                              const int32_t* ids, int64_t n_rows, const float* dEi, const float* dEo, const float* dfb,
                              void* ws, int32_t B_ws, bool prepacked, hipStream_t st) {
+    int rc = cffm_sort_keys_impl(s, ids, n_rows, ws, B_ws, prepacked, st);
+    if (rc) return rc;
+    return cffm_sparse_apply_impl(s, tab, acc, n_rows, dEi, dEo, dfb, ws, B_ws, st);
+}
+
+int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_rows, void* ws, int32_t B_ws, bool prepacked,
+                        hipStream_t st, int64_t id_stride) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (n_rows <= 0) return 0;
@@ -137,14 +160,51 @@ int cffm_sparse_adagrad_impl(const cffm_shape_t* s, const cffm_tables_t* tab, co
     if (e != hipSuccess) return (int)e;
     if (tmp_bytes > (size_t)wl.sort_tmp_bytes) return CFFM_ERR_BAD_SHAPE;
     if (!prepacked) {
-        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ids, keys_in, n_rows);
+        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ids, keys_in, n_rows, id_stride);
         CFFM_CHECK_LAUNCH();
     }
     e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, keys_out, (size_t)n_rows, 0u, (unsigned)(32 + bits), st);
-    if (e != hipSuccess) return (int)e;
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
+                           const float* dEi, const float* dEo, const float* dfb, void* ws, int32_t B_ws, hipStream_t st) {
+    LateScale ls = {nullptr, 0.f, 0};
+    return cffm_sparse_apply_strided(s, tab, acc, n_rows, dEi, s->K, dEo, s->D, dfb, 1, ws, B_ws, ls, st);
+}
+
+int cffm_sparse_apply_strided(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
+                              const float* dEi, int64_t sEi, const float* dEo, int64_t sEo, const float* dfb, int64_t sfb,
+                              void* ws, int32_t B_ws, LateScale ls, hipStream_t st) {
+    if (n_rows <= 0) return 0;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B_ws, &wl);
+    const unsigned long long* keys_out = (const unsigned long long*)((char*)ws + wl.sort_vals);
     hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys_out, n_rows,
                        s->M, s->K, s->D, dEi, dEo, dfb, tab->inner_emb, tab->outer_emb, tab->feat_bias,
-                       acc->inner_emb, acc->outer_emb, acc->feat_bias, s->lr);
+                       acc->inner_emb, acc->outer_emb, acc->feat_bias, s->lr, sEi, sEo, sfb, ls);
     CFFM_CHECK_LAUNCH();
     return 0;
+}
+
+// Data-parallel apply (cffm_amd/dist.py): grad_sum = all-reduced [theta.n gradients | pad | loss-term sum at index
+// theta.n], rows = all-gathered packed rows [n_rows][1 + K + D + 1] = (id bits | dEi | dEo | dfb).
+extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, float* theta,
+                             float* theta_acc, const float* grad_sum, int64_t B_global, const float* rows,
+                             int64_t n_rows, void* ws, int32_t B_ws, float* loss_out, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    cffm_theta_layout_t tl;
+    cffm_theta_layout(s, &tl);
+    LateScale ls = {grad_sum + tl.n, 1.f / (float)B_global, s->loss == CFFM_LOSS_SQUARE_RMSE ? 1 : 0};
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, st, theta, theta_acc,
+                       grad_sum, (int64_t)tl.n, s->lr, ls, loss_out);
+    CFFM_CHECK_LAUNCH();
+    const int64_t W = 1 + s->K + s->D + 1;
+    rc = cffm_sort_keys_impl(s, (const int32_t*)rows, n_rows, ws, B_ws, false, st, W);
+    if (rc) return rc;
+    return cffm_sparse_apply_strided(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws,
+                                     B_ws, ls, st);
 }

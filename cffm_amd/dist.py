@@ -6,11 +6,12 @@ design.  Examples are independent in the forward pass; the only couplings are th
 over the GLOBAL batch, CFFM.py:493) and the parameter gradients:
 
   1. local forward, per-example loss terms                      (no communication)
-  2. all-reduce of ONE scalar: the sum of loss terms            -> global loss L and dL/dout = (out-y)/(Bg*L)
-  3. local backward with that normaliser                        (no communication)
-  4. all-reduce (sum) of the flat dense gradient                (36 K floats at frappe, 5 M at F=32)
+  2. local backward WITHOUT the 1/L normaliser                  (no communication; gradients are linear in dL/dout)
+  3. ONE all-reduce (sum) of the flat dense gradient with the local loss-term sum in a spare slot
+     (41 K floats at frappe, 5 M at F=32)
+  4. 1/L = rsqrt(sum/Bg + 1e-10) is applied to the summed gradients inside the update kernels
   5. sparse tables, two modes:
-       replicated (default while the tables fit one GPU):  all-gather of (ids, row gradients); every rank then
+       replicated (default while the tables fit one GPU):  ONE all-gather of packed (id, row gradients); every rank then
            runs the same sorted segment-sum + Adagrad over the Bg*F rows, so the replicas stay bit-identical;
        row-sharded (``ShardedTables``, vocabulary beyond one GPU's HBM): ids all-to-all to the owner
            (row r lives on rank r % G), owners gather and send rows back, row gradients return by all-to-all and
@@ -24,16 +25,22 @@ import torch.distributed as dist
 
 
 class DataParallelStep(object):
+    """Two collectives per step.  The loss normaliser 1/L (CFFM.py:493) needs the loss-term sum over the GLOBAL
+    batch; instead of a separate scalar all-reduce between forward and backward, the backward pass runs with
+    dL/dout = (out - y) / Bg (every gradient is linear in dL/dout), the local loss-term sum rides in a spare slot of
+    the flat gradient buffer, and 1/L is applied to the summed gradients in the update:
+
+        forward (local) -> backward_unscaled (local) -> all-reduce [grad | loss sum] -> all-gather packed rows
+        (id | dEi | dEo | dfb) -> dp_apply: 1/L, dense Adagrad, sorted duplicates-first sparse Adagrad
+
+    Every rank applies the same update to its replica, so the replicas stay bit-identical."""
+
     def __init__(self, compute, group=None):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-
-    def _all_gather_cat(self, t):
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(parts, t.contiguous(), group=self.group)
-        return torch.cat(parts, dim=0)
+        self._gathered = {}
 
     def train_step(self, ids, y):
         """ids int32 [B,F], y fp32 [B]: this rank's shard of the global batch (same B on every rank).
@@ -42,19 +49,14 @@ class DataParallelStep(object):
         B = ids.shape[0]
         Bg = B * self.world
         c.forward(ids, y)
-        s = c.loss_sum_local(B).clone()                       # [1] sum of per-example loss terms
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
-        c.set_loss_sum_global(B, s)
-        c.backward(y, B, Bg)
-        dist.all_reduce(c.grad, op=dist.ReduceOp.SUM, group=self.group)
-        c.apply_dense()
-        dEi, dEo, dfb = c.row_grads(B)
-        ids_all = self._all_gather_cat(ids.reshape(-1))
-        dEi_all = self._all_gather_cat(dEi.reshape(B * ids.shape[1], -1)) if dEi is not None else None
-        dEo_all = self._all_gather_cat(dEo.reshape(B * ids.shape[1], -1)) if dEo is not None else None
-        dfb_all = self._all_gather_cat(dfb.reshape(-1))
-        c.apply_sparse(ids_all, dEi_all, dEo_all, dfb_all, Bg)
-        return c.loss_value(B)
+        grad, rows = c.backward_unscaled(ids, y, B, Bg)
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+        out = self._gathered.get(rows.shape)
+        if out is None:
+            out = torch.empty((rows.shape[0] * self.world,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+            self._gathered[rows.shape] = out
+        dist.all_gather_into_tensor(out, rows, group=self.group)
+        return c.dp_apply(grad, out, Bg)
 
 
 def shard_of(ids, world):

@@ -45,7 +45,8 @@ class HipEngine(object):
         dev = self.device
         self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
         self.theta_acc = torch.full((n,), ADAGRAD_INIT_ACC, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n + 4, dtype=torch.float32, device=dev)[:n]      # +4: loss-sum slot of the DP step
+        self._grad_full = self.grad._base if self.grad._base is not None else self.grad
         M = cfg.M
         self.inner = torch.zeros((M, cfg.K), dtype=torch.float32, device=dev)
         self.outer = torch.zeros((M, cfg.D), dtype=torch.float32, device=dev)
@@ -210,6 +211,34 @@ class HipEngine(object):
         hip.check(self.lib.cffm_backward(C.byref(self.shape), _ptr(self.theta), _ptr(y), int(B),
                                          int(B if B_global is None else B_global), _ptr(buf), _ptr(self.grad),
                                          self._stream()))
+
+    # ---- data-parallel halves with late loss normalisation (cffm_amd/dist.py) ----------------------------------
+    def backward_unscaled(self, ids, y, B, B_global):
+        """Backward with dL/dout = (out - y) / B_global.  Returns (grad_full [n+4] with this rank's loss-term sum at
+        index n, rows [B*F, 1+K+D+1] = (id bits | dEi | dEo | dfb)) - the operands of ONE all-reduce and ONE
+        all-gather."""
+        ids = self._ids(ids)
+        buf, _ = self.workspace(B)
+        W = 1 + self.cfg.K + self.cfg.D + 1
+        key = ('rows', B)
+        rows = self._ws.get(key)
+        if rows is None:
+            rows = torch.empty((B * self.cfg.F, W), dtype=torch.float32, device=self.device)
+            self._ws[key] = rows
+        hip.check(self.lib.cffm_backward_unscaled(C.byref(self.shape), _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
+                                                  int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(rows),
+                                                  self._stream()))
+        return self._grad_full, rows
+
+    def dp_apply(self, grad_full, rows_all, B_global):
+        n_rows = rows_all.shape[0]
+        B_ws = -(-n_rows // self.cfg.F)
+        buf, _ = self.workspace(B_ws)
+        hip.check(self.lib.cffm_dp_apply(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+                                         _ptr(self.theta), _ptr(self.theta_acc), _ptr(grad_full), int(B_global),
+                                         _ptr(rows_all), int(n_rows), _ptr(buf), int(B_ws), _ptr(self.loss_buf),
+                                         self._stream()))
+        return self.loss_buf
 
     def apply_dense(self):
         hip.check(self.lib.cffm_dense_adagrad(_ptr(self.theta), _ptr(self.theta_acc), _ptr(self.grad),

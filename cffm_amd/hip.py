@@ -68,6 +68,8 @@ PROTOTYPES = {
     'cffm_predict': (C.c_int, [_SH, _TB, _P, _P, C.c_int32, _P, _P, _P]),
     'cffm_forward': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, _P, _P]),
     'cffm_backward': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    'cffm_backward_unscaled': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, _P]),
     'cffm_train_step': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
 }
 

@@ -160,6 +160,16 @@ int cffm_forward(const cffm_shape_t *s, const cffm_tables_t *tab, const float *t
 /* backward half: needs scalars[3] = global loss-term sum (cffm_train_step copies scalars[0] there) */
 int cffm_backward(const cffm_shape_t *s, const float *theta, const float *y, int32_t B, int64_t B_global,
                   void *ws, float *grad, void *stream);
+/* Data-parallel halves (cffm_amd/dist.py).  cffm_backward_unscaled = cffm_backward with dL/dout = (out - y) / B_global,
+ * i.e. without the 1/L of the RMSE-style loss (CFFM.py:493), which needs the loss-term sum over the GLOBAL batch:
+ * grad must hold theta.n + 4 floats, grad[theta.n] receives this rank's loss-term sum so that one all-reduce carries
+ * gradients and sum; rows [B*F][1+K+D+1] receives (id bits | dEi | dEo | dfb) for one all-gather.  cffm_dp_apply takes
+ * the all-reduced grad and the all-gathered rows, applies 1/L and the dense + sparse Adagrad updates. */
+int cffm_backward_unscaled(const cffm_shape_t *s, const float *theta, const int32_t *ids, const float *y, int32_t B,
+                           int64_t B_global, void *ws, float *grad, float *rows, void *stream);
+int cffm_dp_apply(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *acc, float *theta,
+                  float *theta_acc, const float *grad_sum, int64_t B_global, const float *rows, int64_t n_rows,
+                  void *ws, int32_t B_ws, float *loss_out, void *stream);
 /* sess.run((self.loss, self.optimizer)) CFFM.py:200: one fused forward + backward + Adagrad update of
  * theta/tables (and their accumulators) in place; loss (device scalar, may be NULL) receives the loss. */
 int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,

@@ -72,42 +72,36 @@ class OracleCompute(object):
         self.out, self.cache = orc.forward(self.p, self.X, self.cfg)
         self.sc[0] = float(np.sum((y.numpy() - self.out) ** 2))
 
-    def loss_sum_local(self, B):
-        return self.sc[0:1]
-
-    def set_loss_sum_global(self, B, s):
-        self.sc[3:4] = s
-
-    def loss_value(self, B):
-        return self.sc[1:2]
-
-    def backward(self, y, B, Bg):
-        L = np.sqrt(float(self.sc[3]) / Bg + 1e-10)
-        self.sc[1] = L
-        dout = (self.out - y.numpy()) / (Bg * L)
+    def backward_unscaled(self, ids, y, B, Bg):
+        dout = (self.out - y.numpy()) / Bg                       # no 1/L yet
         self.g = orc.backward(self.p, self.cache, dout, self.cfg)
-        self.grad[:] = torch.from_numpy(np.concatenate([np.asarray(self.g[k]).reshape(-1) for k in self.names]))
+        flat = np.concatenate([np.asarray(self.g[k]).reshape(-1) for k in self.names] + [[float(self.sc[0])], [0.0] * 3])
+        X = self.X.reshape(-1, 1).astype(np.float64)            # id column (the product packs the int32 bits)
+        rows = np.concatenate([X, self.g['d_inner_rows'].reshape(len(X), -1), self.g['d_outer_rows'].reshape(len(X), -1),
+                               self.g['d_bias_rows'].reshape(len(X), 1)], axis=1)
+        return torch.from_numpy(flat), torch.from_numpy(np.ascontiguousarray(rows))
 
-    def row_grads(self, B):
-        return tuple(torch.from_numpy(np.ascontiguousarray(self.g[k])) for k in ('d_inner_rows', 'd_outer_rows', 'd_bias_rows'))
-
-    def apply_dense(self):
-        flat, o = self.grad.numpy(), 0
-        for k, n in zip(self.names, self.sizes):
-            gk = flat[o:o + n].reshape(self.p[k].shape)
-            o += n
+    def dp_apply(self, grad, rows_all, Bg):
+        g = grad.numpy()
+        n = sum(self.sizes)
+        L = np.sqrt(g[n] / Bg + 1e-10)
+        flat, o = g[:n] / L, 0
+        for k, sz in zip(self.names, self.sizes):
+            gk = flat[o:o + sz].reshape(self.p[k].shape)
+            o += sz
             if self.p[k].shape == ():
                 a = self.acc[k] + gk * gk
                 self.acc[k] = a
                 self.p[k] = self.p[k] - self.cfg.lr * gk / np.sqrt(a)
             else:
                 orc.adagrad_dense(self.p[k], self.acc[k], gk, self.cfg.lr)
-
-    def apply_sparse(self, ids, dEi, dEo, dfb, B_ws):
-        i = ids.numpy()
-        orc.adagrad_sparse(self.p['inner_embeddings'], self.acc['inner_embeddings'], i, dEi.numpy(), self.cfg.lr)
-        orc.adagrad_sparse(self.p['outer_embeddings'], self.acc['outer_embeddings'], i, dEo.numpy(), self.cfg.lr)
-        orc.adagrad_sparse(self.p['feature_bias'], self.acc['feature_bias'], i, dfb.numpy().reshape(-1, 1), self.cfg.lr)
+        r = rows_all.numpy()
+        ids = r[:, 0].astype(np.int64)
+        K, D = self.cfg.K, self.cfg.D
+        orc.adagrad_sparse(self.p['inner_embeddings'], self.acc['inner_embeddings'], ids, r[:, 1:1 + K] / L, self.cfg.lr)
+        orc.adagrad_sparse(self.p['outer_embeddings'], self.acc['outer_embeddings'], ids, r[:, 1 + K:1 + K + D] / L, self.cfg.lr)
+        orc.adagrad_sparse(self.p['feature_bias'], self.acc['feature_bias'], ids, r[:, 1 + K + D:] / L, self.cfg.lr)
+        return torch.tensor([L])
 
 
 def _case():

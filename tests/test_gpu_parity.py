@@ -314,3 +314,44 @@ def test_full_size_configs(name):
     assert bool((eng.inner_acc[~touched] == 1e-8).all()) and bool((eng.inner_acc[touched] > 1e-8).any(dim=1).all())
     assert bool((eng.outer_acc[~touched] == 1e-8).all()) and bool((eng.fbias_acc[~touched] == 1e-8).all())
     assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
+
+
+def test_data_parallel_halves_on_one_gpu():
+    """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run
+    cffm_backward_unscaled on the two halves of a batch, the test plays the role of the two collectives (sum of the
+    flat gradient buffers, concatenation of the packed rows), and cffm_dp_apply on each replica must reproduce one
+    oracle step on the whole batch - including duplicates of an id that sit on different ranks."""
+    cfg, p32, X, y = make_case('bookx-relu')
+    B = X.shape[0]
+    h = B // 2
+    engines = [engine_for(cfg, p32), engine_for(cfg, p32)]
+    ids = [torch.from_numpy(X[:h]).cuda(), torch.from_numpy(X[h:]).cuda()]
+    ys = [torch.from_numpy(y[:h]).cuda(), torch.from_numpy(y[h:]).cuda()]
+    grads, rows = [], []
+    for e, i, t in zip(engines, ids, ys):
+        e.forward(i, t)
+        g, r = e.backward_unscaled(i, t, h, B)
+        grads.append(g.clone()); rows.append(r.clone())
+    torch.cuda.synchronize()
+    gsum = grads[0] + grads[1]                       # all-reduce
+    rall = torch.cat(rows, dim=0).contiguous()       # all-gather
+    p64 = to64(p32)
+    hook = None
+    grads_ref = oracle_dense_grads(p64, X, y, cfg)
+    acc = orc.init_accumulators(p64)
+    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
+    outs = []
+    for e in engines:
+        loss = e.dp_apply(gsum.clone(), rall, B)
+        torch.cuda.synchronize()
+        close(loss.cpu().numpy(), [L], 'loss')
+        outs.append(e.export_params())
+    for k, v in outs[0].items():
+        np.testing.assert_array_equal(v, outs[1][k], err_msg=k)          # replicas stay bit-identical
+        extra = None
+        if k in grads_ref:
+            gk = grads_ref[k].reshape(v.shape)
+            dg = 2e-5 * max(np.abs(gk).max(), 1e-30)
+            u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
+            extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
+        close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
