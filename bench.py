@@ -80,10 +80,16 @@ def gather_roofline(device):
     assert torch.equal(Eo[5], outer[ids[state['i']][5].long()])
     bytes_per_launch = B * (F * (K + D + 1) * 4 + F * 4)
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+    traffic = None                     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_gather_pmc.json')) as fh:
+            traffic = int(json.load(fh)['hbm_bytes_per_launch'])
+    except Exception:
+        pass
     del inner, outer, fbias, Ei, Eo, fb
     torch.cuda.empty_cache()
     return {'bound': 'hbm', 'kernel': 'gather_rows_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
             'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 2),
             'workload': 'synthetic libfm 32 fields dim 64 1M features batch 8192 uniform ids (tables 516 MB)'}
 

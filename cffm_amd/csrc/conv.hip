@@ -694,11 +694,11 @@ __global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
 // accumulators.
 template <int NT, int RM, bool GEN>
 __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
-    constexpr int PP = NT * 16, LDW = PP + 4, BM = 64 * RM;
+    constexpr int PP = NT * 16, BM = 64 * RM;
     constexpr int NW4 = 4 * PP * PP / 4 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][LDW]
-    uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
+    float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP], columns rotated by 16 on rows with bit 2 set
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * PP);       // [PP]            (GEN)
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1;
@@ -737,8 +737,10 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-        const int u = tid + 256 * i, row = u / (PP / 4), c4 = u % (PP / 4);
-        *reinterpret_cast<float4*>(&Wl[row * LDW + 4 * c4]) = wv[i];
+        const int u = tid + 256 * i, row = u / (PP / 4);
+        int cc = 4 * (u % (PP / 4)) + ((row >> 2) & 1) * 16;      // unpadded rows stay conflict-free for the B reads:
+        if (cc >= PP) cc -= PP;                                   // the two k rows of a half-wave use disjoint bank halves
+        *reinterpret_cast<float4*>(&Wl[row * PP + cc]) = wv[i];
     }
     __syncthreads();
 
@@ -747,6 +749,12 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int bcol[NT];                    // rows 4*kk+t have bit 2 = kk & 1 -> their columns are rotated by 16
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = nt * 16 + r + (kk & 1) * 16;
+        bcol[nt] = c >= PP ? c - PP : c;
+    }
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
         const int dh = tap >> 1, dw = tap & 1;
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
                 const int krow = tap * PP + 16 * h + 4 * kk + t;
                 float bf[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[nt] = Wl[krow * LDW + nt * 16 + r];
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = Wl[krow * PP + bcol[nt]];
 #pragma unroll
                 for (int rm = 0; rm < RM; ++rm) {
                     const float x = t == 0 ? x4[rm].x : t == 1 ? x4[rm].y : t == 2 ? x4[rm].z : x4[rm].w;
@@ -1285,7 +1293,7 @@ static int launch_conv_fwd_rows(const ConvArgs& a, hipStream_t st) {
     constexpr int PP = NT * 16, BM = 64 * RM;
     const int S2 = 1 << (2 * a.lgSo);
     const int n_ex = GEN ? (BM > S2 ? BM / S2 : 1) : 0;
-    const size_t lds = (size_t)4 * PP * (PP + 4) * 4 + (size_t)(GEN ? PP + n_ex * a.F * (a.D + 1) : 0) * 4 + 16;
+    const size_t lds = (size_t)4 * PP * PP * 4 + (size_t)(GEN ? PP + n_ex * a.F * (a.D + 1) : 0) * 4 + 16;
     int rc = set_lds(conv_fwd_rows_kernel<NT, RM, GEN>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((conv_fwd_rows_kernel<NT, RM, GEN>), dim3((unsigned)((a.Mtot + BM - 1) / BM)), dim3(256), lds, st, a);
