@@ -807,6 +807,387 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
         }
 }
 
+// conv0_fact_fwd: layer 0 in FACTORISED form (small Pp).  The input channels of layer 0 are rank-1,
+// A[(y,x),(dh,dw,(i,j))] = E[i][2y+dh] * E[j][2x+dw], so the contraction splits exactly:
+//     T[dh][i][x][q] = sum_{dw} sum_{j>i} E[j][2x+dw] * W[dh][dw][(i,j)][q]          step 1: 4*S*P^2 MACs
+//     C[y][x][q]     = relu(b[q] + sum_{dh} sum_i E[i][2y+dh] * T[dh][i][x][q])       step 2: 2*F*S^2*P MACs
+// against S^2 * 4P * P for the direct form: 5.8x fewer MFMAs at frappe (F10 D32), executed on the same
+// v_mfma_f32_16x16x4_f32.  One workgroup per example: the embedding tile, the whole filter (36 KB) and T
+// (2F x S x Pp floats, 61 KB at frappe) live in LDS; nothing but C goes back to HBM.
+//   step 1, unit (dh, i, nt): rows x, k = (dw, j > i) - the pairs of a fixed i are CONTIGUOUS filter rows;
+//                             A fragment = one ds_read of E, B fragment = one ds_read of the staged filter.
+//   step 2, wave w owns x = w, w+4, ...: rows y, k = (dh, i), B fragment = T[(dh,i)][x][q] (row pitch padded by
+//                             16 floats so the two k rows of a half-wave hit disjoint banks).
+template <int NT>
+__global__ __launch_bounds__(256) void conv0_fact_fwd_kernel(ConvArgs a) {
+    constexpr int PP = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16;
+    const int TP = S * PP + 16;                                 // pitch of one (dh, i) plane of T
+    float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP]
+    float* T = Wl + 4 * PP * PP;                                // [2F][TP]
+    float* Es = T + 2 * F * TP;                                 // [F][Dp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.x;
+    {   // stage the filter and the embedding tile (one barrier)
+        const float4* wsrc = reinterpret_cast<const float4*>(a.W);
+        for (int i = tid; i < 4 * PP * PP / 4; i += 256) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
+        const float* e = a.in + (int64_t)b * F * D;
+        const float invD = 1.f / (float)D;
+        for (int i = tid; i < F * D; i += 256) {
+            const int f = fast_div(i, invD), d = i - f * D;
+            Es[f * Dp + d] = e[i];
+        }
+    }
+    __syncthreads();
+    // ---- step 1: unit (dh, i, rt) with all NT column tiles at once (one A fragment feeds NT MFMAs) ---------------
+    const int units = 2 * (F - 1) * RT;
+    for (int u = wave; u < units; u += 4) {
+        int t = u;
+        const int rt = t % RT; t /= RT;
+        const int i = t % (F - 1), dh = t / (F - 1);
+        const int nj = F - 1 - i, K = 2 * nj;                   // k = dw * nj + (j - i - 1)
+        const int base = i * (2 * F - i - 1) / 2;               // first pair (i, i+1)
+        const int x = rt * 16 + r;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + kk;
+            const bool ok = k < K;
+            const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
+            const float av = ok ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
+            const float* wr = Wl + ((dh * 2 + dw) * PP + base + jj) * PP + r;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av, ok ? wr[nt * 16] : 0.f, acc[nt]);
+        }
+        float* tp = T + (dh * F + i) * TP + r;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tp[(rt * 16 + kk * 4 + j) * PP + nt * 16] = acc[nt][j];
+    }
+    // planes (dh, F-1) have no pairs: zero them so that step 2 can run a dense k
+    for (int e = tid; e < 2 * S * PP; e += 256) {
+        const int dh = e / (S * PP), o = e - dh * (S * PP);
+        T[(dh * F + F - 1) * TP + o] = 0.f;
+    }
+    __syncthreads();
+    // ---- step 2: a wave takes four x at a time (one A fragment feeds 4*NT MFMAs) ----------------------------------
+    const int K2 = 2 * F, ks2 = (K2 + 3) / 4;
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias[nt * 16 + r];
+    for (int rt = 0; rt < RT; ++rt) {
+        const int y = rt * 16 + r;
+        for (int xg = wave * 4; xg < S; xg += 16) {
+            f32x4 acc[4][NT];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[q4][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < ks2; ++s2) {
+                const int k = 4 * s2 + kk;
+                const bool ok = k < K2;
+                const int dh = (ok && k >= F) ? 1 : 0, i = ok ? k - dh * F : 0;
+                const float av = ok ? Es[i * Dp + 2 * y + dh] : 0.f;
+                const float* tb = T + (ok ? k : 0) * TP + xg * PP + r;
+                float bv[4][NT];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[q4][nt] = ok ? tb[q4 * PP + nt * 16] : 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[q4][nt] = mfma16(av, bv[q4][nt], acc[q4][nt]);
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int yy = rt * 16 + kk * 4 + j;
+                        a.out[(((int64_t)b * S + yy) * S + xg + q4) * PP + nt * 16 + r] = fmaxf(acc[q4][nt][j] + bias[nt], 0.f);
+                    }
+        }
+    }
+}
+
+// conv0_fact_bwd: the whole backward of layer 0 in factorised form (S = 16, small Pp), one workgroup per
+// gradient slab looping over its examples.  With T as in conv0_fact_fwd and dC the gradient wrt the pre-relu
+// conv output:
+//   A  T[dh][i][x][q]   recomputed (150 MFMAs at frappe)                                   -> LDS
+//   B  dEi[(dh,i)][y]   = sum_{x,q} dC[y][x][q] * T[dh][i][x][q]        rows y, k = (x,q), cols (dh,i)
+//   C  dT[dh][i][x][q]  = sum_y E[i][2y+dh] * dC[y][x][q]               rows (dh,i), k = y, cols (x,q) -> LDS (over T)
+//      db[q]            = sum_{y,x} dC[y][x][q]                         (from the B fragments of C)
+//   D  dW[dh][dw][(i,j)][q] += sum_x E[j][2x+dw] * dT[dh][i][x][q]      rows (dw,j>i), k = x, cols q -> slab
+//   E  dEj[(dw,j)][x]   = sum_{dh,i<j,q} dT[dh][i][x][q] * W[dh][dw][(i,j)][q]   rows x, k = q, cols (dw,j)
+//   F  dEo[f][h] = dEi[(h&1,f)][h>>1] + dEj[(h&1,f)][h>>1] + ds0[h]*R_f + Q_f  (s0 pool gradient in closed form)
+// ~1640 MFMAs per example against 4608 for the direct wgrad + dgrad, no atomics, fixed summation order.
+template <int NT>
+__global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float* __restrict__ slabW,
+                                                              float* __restrict__ slabB, int64_t slab_stride) {
+    constexpr int PP = NT * 16, S = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, Dp = D + 1, P = a.P, F2 = 2 * F;
+    const int TP = S * PP + 16;
+    float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP]
+    float* T = Wl + 4 * PP * PP;                                // [2F][TP]   T, later dT
+    float* part = T + 2 * F * TP;                               // [4 waves][16][32] partial tiles (phases B, E)
+    float* dEi = part + 4 * 16 * 32;                            // [32][16]  (n = (dh,i), y)
+    float* dEj = dEi + 32 * 16;                                 // [32][16]  (n = (dw,j), x)
+    float* bred = dEj + 32 * 16;                                // [4][PP] bias partials
+    float* rs = bred + 4 * PP;                                  // [F] row sums, [F] dots
+    float* Es = rs + 2 * F;                                     // [F][Dp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    float* sw = slabW + (int64_t)blockIdx.x * slab_stride;
+    float* sb = slabB + (int64_t)blockIdx.x * slab_stride;
+    {
+        const float4* wsrc = reinterpret_cast<const float4*>(a.W);
+        for (int i = tid; i < 4 * PP * PP / 4; i += 256) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
+        // rows of padded pairs (p >= P) are never produced below: they must read as zeros in the reduction
+        for (int e = tid; e < 4 * (PP - P) * PP; e += 256) {
+            const int tap = e / ((PP - P) * PP), o = e - tap * ((PP - P) * PP);
+            sw[(tap * PP + P) * PP + o] = 0.f;
+        }
+    }
+    bool first = true;
+    float bacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bacc[nt] = 0.f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        {
+            const float* e = a.Cprev + (int64_t)b * F * D;      // Eo rows of this example
+            const float invD = 1.f / (float)D;
+            for (int i = tid; i < F * D; i += 256) {
+                const int f = fast_div(i, invD), d = i - f * D;
+                Es[f * Dp + d] = e[i];
+            }
+        }
+        __syncthreads();
+        const float* dCb = a.dC + (int64_t)b * S * S * PP;
+        // ---- A: T ----------------------------------------------------------------------------------------------
+        for (int u = wave; u < 2 * (F - 1); u += 4) {
+            const int i = u % (F - 1), dh = u / (F - 1);
+            const int nj = F - 1 - i, K = 2 * nj, base = i * (2 * F - i - 1) / 2;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                const int k = k0 + kk;
+                const bool ok = k < K;
+                const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
+                const float av = ok ? Es[(i + 1 + jj) * Dp + 2 * r + dw] : 0.f;
+                const float* wr = Wl + ((dh * 2 + dw) * PP + base + jj) * PP + r;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av, ok ? wr[nt * 16] : 0.f, acc[nt]);
+            }
+            float* tp = T + (dh * F + i) * TP + r;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tp[(kk * 4 + j) * PP + nt * 16] = acc[nt][j];
+        }
+        for (int e = tid; e < 2 * S * PP; e += 256) {
+            const int dh = e / (S * PP), o = e - dh * (S * PP);
+            T[(dh * F + F - 1) * TP + o] = 0.f;
+        }
+        __syncthreads();
+        // ---- B: dEi = dC (rows y) x T^T, this wave's k = its four x -----------------------------------------------
+        {
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            float4 av[4][NT];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int h = 0; h < NT; ++h)
+                    av[q4][h] = *reinterpret_cast<const float4*>(dCb + ((int64_t)r * S + wave + 4 * q4) * PP + 16 * h + 4 * kk);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int x = wave + 4 * q4;
+#pragma unroll
+                for (int h = 0; h < NT; ++h) {
+                    float4 bv[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const int n = ct * 16 + r;
+                        bv[ct] = n < F2 ? *reinterpret_cast<const float4*>(T + n * TP + x * PP + 16 * h + 4 * kk)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        acc[ct] = mfma16(av[q4][h].x, bv[ct].x, acc[ct]);
+                        acc[ct] = mfma16(av[q4][h].y, bv[ct].y, acc[ct]);
+                        acc[ct] = mfma16(av[q4][h].z, bv[ct].z, acc[ct]);
+                        acc[ct] = mfma16(av[q4][h].w, bv[ct].w, acc[ct]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(wave * 16 + kk * 4 + j) * 32 + ct * 16 + r] = acc[ct][j];
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * 32; e += 256) {               // e = y * 32 + n
+            const float v = ((part[e] + part[512 + e]) + part[1024 + e]) + part[1536 + e];
+            dEi[(e & 31) * 16 + (e >> 5)] = v;
+        }
+        __syncthreads();                                          // T fully consumed: phase C may overwrite it
+        // ---- C: dT = E^T (rows (dh,i)) x dC, this wave's columns = its four x; db from the B fragments ------------
+        {
+            float av[2][4];                                      // A[m = rt*16 + r][k = y = 4s + kk]
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int m = rt * 16 + r, dh = m >= F ? 1 : 0, i = m - dh * F;
+                    av[rt][s4] = m < F2 ? Es[i * Dp + 2 * (4 * s4 + kk) + dh] : 0.f;
+                }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int x = wave + 4 * q4;
+                float bv[4][NT];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[s4][nt] = dCb[((int64_t)(4 * s4 + kk) * S + x) * PP + nt * 16 + r];
+                f32x4 acc[2][NT];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        bacc[nt] += bv[s4][nt];
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = mfma16(av[rt][s4], bv[s4][nt], acc[rt][nt]);
+                    }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = rt * 16 + kk * 4 + j;
+                            if (m < F2) T[m * TP + x * PP + nt * 16 + r] = acc[rt][nt][j];
+                        }
+            }
+        }
+        __syncthreads();
+        // ---- D: dW slab rows (dh, dw, (i, j>i)) ---------------------------------------------------------------------
+        {
+            int ucount = 0;
+            for (int dh = 0; dh < 2; ++dh)
+                for (int i = 0; i < F - 1; ++i) {
+                    const int nj = F - 1 - i, K = 2 * nj, base = i * (2 * F - i - 1) / 2;
+                    for (int rt = 0; rt * 16 < K; ++rt, ++ucount) {
+                        if ((ucount & 3) != wave) continue;
+                        const int m = rt * 16 + r;
+                        const bool okm = m < K;
+                        const int dw = (okm && m >= nj) ? 1 : 0, jj = okm ? m - dw * nj : 0;
+                        f32x4 acc[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int x = 4 * s4 + kk;
+                            const float avv = okm ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
+                            const float* tb = T + (dh * F + i) * TP + x * PP + r;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(avv, tb[nt * 16], acc[nt]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int mm = rt * 16 + kk * 4 + j;
+                            if (mm < K) {
+                                const int dw2 = mm >= nj ? 1 : 0, jj2 = mm - dw2 * nj;
+                                float* dst = sw + ((dh * 2 + dw2) * PP + base + jj2) * PP + r;
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) dst[nt * 16] = first ? acc[nt][j] : dst[nt * 16] + acc[nt][j];
+                            }
+                        }
+                    }
+                }
+        }
+        // ---- E: dEj = dT (rows x) x W^T over this wave's (dh, i) units -------------------------------------------------
+        {
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            for (int u = wave; u < 2 * (F - 1); u += 4) {
+                const int i = u % (F - 1), dh = u / (F - 1), base = i * (2 * F - i - 1) / 2;
+                const float* ta = T + (dh * F + i) * TP + r * PP + 4 * kk;
+                const float* wrow[2];
+                bool okc[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int n = ct * 16 + r, dw = n >= F ? 1 : 0, j = n - dw * F;
+                    okc[ct] = n < F2 && j > i;
+                    wrow[ct] = Wl + ((dh * 2 + dw) * PP + base + (okc[ct] ? j - i - 1 : 0)) * PP + 4 * kk;
+                }
+#pragma unroll
+                for (int h = 0; h < NT; ++h) {
+                    const float4 av = *reinterpret_cast<const float4*>(ta + 16 * h);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const float4 bv = okc[ct] ? *reinterpret_cast<const float4*>(wrow[ct] + 16 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        acc[ct] = mfma16(av.x, bv.x, acc[ct]);
+                        acc[ct] = mfma16(av.y, bv.y, acc[ct]);
+                        acc[ct] = mfma16(av.z, bv.z, acc[ct]);
+                        acc[ct] = mfma16(av.w, bv.w, acc[ct]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(wave * 16 + kk * 4 + j) * 32 + ct * 16 + r] = acc[ct][j];
+        }
+        if (tid < 2 * F) {                                       // row sums and <ds0, E[f]> for the closed-form s0 terms
+            const int f = tid % F;
+            float sacc = 0.f;
+            if (tid < F) { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h]; }
+            else { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h] * a.dt1[(int64_t)b * a.t1w + h]; }
+            rs[tid] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * 32; e += 256) {               // e = x * 32 + n
+            const float v = ((part[e] + part[512 + e]) + part[1024 + e]) + part[1536 + e];
+            dEj[(e & 31) * 16 + (e >> 5)] = v;
+        }
+        __syncthreads();
+        // ---- F -----------------------------------------------------------------------------------------------------
+        for (int e = tid; e < F * D; e += 256) {
+            const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
+            float R = 0.f, Q = 0.f;
+            for (int j = f + 1; j < F; ++j) R += rs[j];
+            for (int i = 0; i < f; ++i) Q += rs[F + i];
+            a.dprev[(int64_t)b * F * D + e] = (dEi[(lo * F + f) * 16 + hh] + dEj[(lo * F + f) * 16 + hh])
+                                              + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+        }
+        first = false;
+    }
+    // ---- bias gradient and empty-slab zeros -----------------------------------------------------------------------------
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v = bacc[nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (kk == 0) bred[wave * PP + nt * 16 + r] = v;
+    }
+    __syncthreads();
+    if (tid < PP) sb[tid] = ((bred[tid] + bred[PP + tid]) + bred[2 * PP + tid]) + bred[3 * PP + tid];
+    if (first) {                                                  // no example for this slab
+        for (int e = tid; e < 4 * PP * PP; e += 256) sw[e] = 0.f;
+    }
+}
+
 // HALVES = 2 (layer 0 only): 8 wavefronts, the upper four take the second half of the workgroup's m tiles, so
 // that every SIMD has two wavefronts whose MFMA and epilogue phases can overlap.
 //
@@ -1301,6 +1682,45 @@ static int launch_conv_fwd_rows(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int NT>
+static int launch_conv0_fact_fwd(const ConvArgs& a, hipStream_t st) {
+    constexpr int PP = NT * 16;
+    const int S = a.D / 2;
+    const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (S * PP + 16) + a.F * (a.D + 1)) * 4 + 16;
+    int rc = set_lds(conv0_fact_fwd_kernel<NT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv0_fact_fwd_kernel<NT>), dim3(a.B), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// the factorised layer-0 kernels keep the filter, the embedding tile and T[2F][S][Pp] of one example in LDS
+static inline bool conv0_fact_ok(const Geo& g) {
+    const int S = g.D / 2;
+    if (g.Pp > 64 || (S != 16 && S != 32)) return false;
+    const size_t lds = (size_t)(4 * g.Pp * g.Pp + 2 * g.F * (S * g.Pp + 16) + g.F * (g.D + 1)) * 4 + 16;
+    return lds <= 150 * 1024;
+}
+
+static inline bool conv0_fact_bwd_ok(const Geo& g) {
+    if (g.Pp > 64 || g.D != 32) return false;
+    const size_t lds = (size_t)(4 * g.Pp * g.Pp + 2 * g.F * (16 * g.Pp + 16) + 4 * 16 * 32 + 2 * 32 * 16 + 4 * g.Pp + 2 * g.F +
+                                g.F * (g.D + 1)) * 4 + 16;
+    return lds <= 150 * 1024;
+}
+
+template <int NT>
+static int launch_conv0_fact_bwd(const DgradArgs& a, float* slabW, float* slabB, int64_t stride, int nsl, hipStream_t st) {
+    constexpr int PP = NT * 16;
+    const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (16 * PP + 16) + 4 * 16 * 32 + 2 * 32 * 16 + 4 * PP + 2 * a.F +
+                                a.F * (a.D + 1)) * 4 + 16;
+    int rc = set_lds(conv0_fact_bwd_kernel<NT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv0_fact_bwd_kernel<NT>), dim3(nsl), dim3(256), lds, st, a, slabW, slabB, stride);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int NT, int RM, bool L0, int HALVES>
 static int launch_dgrad_taps(const DgradArgs& a, hipStream_t st) {
     constexpr int PP = NT * 16, BM = 16 * RM;
@@ -1376,6 +1796,10 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop
         const int nt4 = g.Pp / 16;
         const int64_t wg16 = (a.Mtot + 15) / 16;
+        if (l == 0 && conv0_fact_ok(g)) {        // rank-1 input channels: factorised contraction, one workgroup per example
+            DISPATCH_NT4(nt4, rc = (launch_conv0_fact_fwd<NT_>(a, st)));
+            return rc;
+        }
         if (wg16 >= 4 * 512) {                    // many rows: whole filter in LDS, a wave runs all four taps
             if (l == 0) { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_rows<NT_, 1, true>(a, st))); }
             else { DISPATCH_NT4(nt4, rc = (launch_conv_fwd_rows<NT_, 1, false>(a, st))); }
@@ -1417,6 +1841,20 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     make_slab_plan(s, B, tl, &sp);
     const SlabRange& sr = sp.r[sp.conv0 + l];
     int rc = 0;
+    if (l == 0 && which == 3 && conv0_fact_bwd_ok(g)) {   // factorised layer 0: weight, bias and input gradient in one kernel
+        DgradArgs a;
+        a.dC = (const float*)(w + wl.dC[0]);
+        a.W = theta + tl.conv_w[0];
+        a.Cprev = (const float*)(w + wl.Eo);
+        a.dt1 = (const float*)(w + wl.dt1);
+        a.dprev = (float*)(w + wl.dEo);
+        a.Mtot = layer_rows(g, B, 0, &a.lgSo);
+        a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+        a.t1w = 2 * g.D - 2; a.t1off = 0;
+        float* slabW = gpart + sr.base;
+        DISPATCH_NT4(g.Pp / 16, rc = (launch_conv0_fact_bwd<NT_>(a, slabW, slabW + (tl.conv_b[0] - tl.conv_w[0]), sr.len, sr.nslab, st)));
+        return rc;
+    }
     if (which & 1) {   // weight / bias gradient
         WgradArgs a;
         a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
