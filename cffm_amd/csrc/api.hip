@@ -188,12 +188,21 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
                                float* theta, float* theta_acc, float* grad, const int32_t* ids, const float* y,
                                int32_t B, void* ws, float* loss, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    int rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);
-    if (rc || B <= 0) return rc;
-    if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
     cffm_ws_layout_t wl;
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
+    if (cffm_fwd_all_ok(s, B)) {                 // small-channel shapes: the whole forward (and the key sort) in one launch
+        if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st))) return rc;
+        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
+        return cffm_sparse_apply_impl(s, tab, tab_acc, (int64_t)B * s->F, (const float*)(w + wl.dEi),
+                                      (const float*)(w + wl.dEo), (const float*)(w + wl.dfb), ws, B, st);
+    }
+    rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);
+    if (rc) return rc;
+    if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
     return cffm_sparse_adagrad_impl(s, tab, tab_acc, ids, (int64_t)B * s->F,
                                     s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
                                     s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),

@@ -20,6 +20,9 @@
 // Channels are padded to Pp = ceil16(P) in every activation tensor so that 16-byte pieces never
 // straddle a row and tiles never straddle a filter tap; padded channels hold zeros.
 #include "internal.hpp"
+#include "inner_body.hpp"
+#include "head_body.hpp"
+#include "sort_body.hpp"
 
 #define KSTEP 32
 #define WG_KM 64       // rows of the M (reduction) dimension staged per wgrad step
@@ -573,17 +576,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 //   dgrad_taps    : wave t produces the gradient of tap t's input positions; the B fragments are rows of W
 //                   read straight from L2 as 16-byte pieces (no LDS, no barrier at all for L0 = false).
 // =================================================================================================
+// rows [m0, m0 + 16*RM) clipped to m_hi (the fused forward kernel passes the rows of ONE example)
 template <int NT, int RM, bool GEN>
-__global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0, int64_t m_hi, char* smem) {
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
     constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
     uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
     const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int b0 = (int)(m0 >> (2 * a.lgSo));
 
     // ---- issue every global load of this wave ----------------------------------------------------------
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             int64_t m = m0 + rm * 16 + r;
-            if (m >= a.Mtot) m = a.Mtot - 1;
+            if (m >= m_hi) m = m_hi - 1;
             const RowPos rp = row_pos(m, a.lgSo);
             const float* src = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + 4 * kk;
 #pragma unroll
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             int64_t m = m0 + rm * 16 + r;
-            if (m >= a.Mtot) m = a.Mtot - 1;
+            if (m >= m_hi) m = m_hi - 1;
             const RowPos rp = row_pos(m, a.lgSo);
             const int eoff = (rp.b - b0) * a.F * Dp;
             const int iy = eoff + 2 * rp.y + dh, jx = eoff + 2 * rp.x + dw;
@@ -683,9 +685,15 @@ __global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0 + rm * 16 + (ln >> 4) * 4 + j;
-            if (m < a.Mtot) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
+            if (m < m_hi) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
         }
     }
+}
+
+template <int NT, int RM, bool GEN>
+__global__ __launch_bounds__(256) void conv_fwd_taps_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_fwd_taps_body<NT, RM, GEN>(a, (int64_t)blockIdx.x * (16 * RM), a.Mtot, smem);
 }
 
 // conv_fwd_rows: many-row variant of the small-Pp forward (layer 0 at frappe: 65536 rows).  The whole padded
@@ -819,16 +827,14 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
 //   step 2, wave w owns x = w, w+4, ...: rows y, k = (dh, i), B fragment = T[(dh,i)][x][q] (row pitch padded by
 //                             16 floats so the two k rows of a half-wave hit disjoint banks).
 template <int NT>
-__global__ __launch_bounds__(256) void conv0_fact_fwd_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem) {
     constexpr int PP = NT * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16;
     const int TP = S * PP + 16;                                 // pitch of one (dh, i) plane of T
     float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP]
     float* T = Wl + 4 * PP * PP;                                // [2F][TP]
     float* Es = T + 2 * F * TP;                                 // [F][Dp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
-    const int b = blockIdx.x;
     {   // stage the filter and the embedding tile (one barrier)
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
         for (int i = tid; i < 4 * PP * PP / 4; i += 256) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
@@ -913,6 +919,60 @@ __global__ __launch_bounds__(256) void conv0_fact_fwd_kernel(ConvArgs a) {
                     }
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv0_fact_fwd_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv0_fact_fwd_body<NT>(a, blockIdx.x, smem);
+}
+
+// =================================================================================================
+// fwd_all: the whole forward of the fused train step in ONE launch (small Pp, D = 32/64 with factorisable layer 0).
+// Workgroup b < B runs example b end to end - gather + inner branch, factorised layer 0, the remaining conv
+// layers (tap-split, rows of this example only), pooling + heads + loss term - with every intermediate that
+// the backward pass needs written to the workspace exactly as the separate kernels write it.  A workgroup only
+// ever re-reads global data it wrote itself (its own C_l rows), which __syncthreads() orders.  Workgroup B sorts
+// the packed (id, slot) keys of the sparse update straight from the ids, so the sort costs no launch either.
+// At the frappe shape this replaces 7 launches (~4 us of dispatch + drain each) by one.
+// =================================================================================================
+struct FwdAllArgs {
+    InnerFwdArgs inner;
+    ConvArgs conv[CFFM_MAX_LAYERS];
+    HeadArgs head;
+    const int32_t* ids;
+    unsigned long long* keys_sorted;
+    int live, n_rows, id_bits, B;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void fwd_all_kernel(FwdAllArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (b == fa.B) {                                   // the extra workgroup: stable sort of the sparse-update keys
+        small_sort_body(nullptr, fa.ids, fa.keys_sorted, fa.n_rows, fa.id_bits, smem);
+        return;
+    }
+    inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b, inner_out[b]
+    __syncthreads();
+    conv0_fact_fwd_body<NT>(fa.conv[0], b, smem);      // reads Eo[b] (written above), writes C_0[b]
+    for (int l = 1; l < fa.live; ++l) {
+        __syncthreads();
+        const ConvArgs& ca = fa.conv[l];
+        const int64_t rows = 1ll << (2 * ca.lgSo), m_lo = (int64_t)b * rows, m_hi = m_lo + rows;
+        if (rows >= 64) {
+            for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
+                if (m0 > m_lo) __syncthreads();
+                conv_fwd_taps_body<NT, 4, false>(ca, m0, m_hi, smem);
+            }
+        } else if (rows >= 32) {
+            conv_fwd_taps_body<NT, 2, false>(ca, m_lo, m_hi, smem);
+        } else {
+            conv_fwd_taps_body<NT, 1, false>(ca, m_lo, m_hi, smem);
+        }
+    }
+    __syncthreads();
+    head_fwd_body(fa.head, b, smem);
 }
 
 // conv0_fact_bwd: the whole backward of layer 0 in factorised form (S = 16, small Pp), one workgroup per
@@ -1943,4 +2003,77 @@ extern "C" int cffm_conv_bwd(const cffm_shape_t* s, const float* theta, void* ws
     if (B <= 0 || !s->outer_conv) return 0;
     if (layer < 1) return CFFM_ERR_BAD_SHAPE;
     return conv_bwd_any(s, theta, ws, B, layer, (hipStream_t)stream);
+}
+
+// ---- fused forward (one launch) --------------------------------------------------------------------------------------
+bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B) {
+    const Geo g = make_geo(s);
+    return s->inner_conv && s->outer_conv && g.Pp <= 64 && conv0_fact_ok(g) && (int64_t)B * s->F <= 4096;
+}
+
+template <int NT>
+static int launch_fwd_all(const FwdAllArgs& fa, size_t lds, hipStream_t st) {
+    int rc = set_lds(fwd_all_kernel<NT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fwd_all_kernel<NT>), dim3(fa.B + 1), dim3(256), lds, st, fa);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                      const float* y, int32_t B, void* ws, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    char* w = (char*)ws;
+    FwdAllArgs fa;
+    // inner branch + gather
+    fa.inner.g = g; fa.inner.Ei = (const float*)(w + wl.Ei);
+    fa.inner.cw = theta + tl.inner_cw; fa.inner.cb = theta + tl.inner_cb; fa.inner.wd = theta + tl.inner_dw;
+    fa.inner.bd = theta + tl.inner_db; fa.inner.inner_out = (float*)(w + wl.inner_out);
+    fa.inner.fg.ids = ids; fa.inner.fg.inner = tab->inner_emb; fa.inner.fg.outer = tab->outer_emb;
+    fa.inner.fg.fbias = tab->feat_bias; fa.inner.fg.Ei = (float*)(w + wl.Ei); fa.inner.fg.Eo = (float*)(w + wl.Eo);
+    fa.inner.fg.fb = (float*)(w + wl.fb); fa.inner.fg.keys = (unsigned long long*)(w + wl.sort_keys);
+    fa.inner.fg.M = s->M; fa.inner.fg.D = s->D;
+    // conv stack
+    for (int l = 0; l < g.live; ++l) {
+        ConvArgs& a = fa.conv[l];
+        a.in = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
+        a.W = theta + tl.conv_w[l]; a.bias = theta + tl.conv_b[l];
+        a.out = (float*)(w + wl.C[l]);
+        a.Mtot = layer_rows(g, B, l, &a.lgSo);
+        a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+    }
+    // head
+    HeadArgs& h = fa.head;
+    h.g = g; h.B = B;
+    h.Eo = (const float*)(w + wl.Eo); h.fb = (const float*)(w + wl.fb); h.inner_out = (const float*)(w + wl.inner_out);
+    for (int l = 0; l < CFFM_MAX_LAYERS; ++l) h.C[l] = (const float*)(w + wl.C[l]);
+    h.d1_w = theta + tl.d1_w; h.d1_b = theta + tl.d1_b; h.d2_w = theta + tl.d2_w; h.d2_b = theta + tl.d2_b;
+    h.att_W = theta + tl.att_W; h.att_b = theta + tl.att_b; h.lin_w = theta + tl.lin_w; h.lin_b = theta + tl.lin_b;
+    h.bias = theta + tl.bias;
+    h.y = y;
+    h.t1 = (float*)(w + wl.t1); h.h1 = (float*)(w + wl.h1); h.att = (float*)(w + wl.att);
+    h.out = (float*)(w + wl.out); h.sqerr = (float*)(w + wl.sqerr);
+    h.loss = s->loss; h.inner_conv = s->inner_conv; h.outer_conv = s->outer_conv;
+    // sort workgroup
+    fa.ids = ids; fa.keys_sorted = (unsigned long long*)(w + wl.sort_vals);
+    fa.live = g.live; fa.n_rows = B * s->F; fa.B = B;
+    int bits = 1;
+    while ((1ll << bits) < (long long)s->M && bits < 31) ++bits;
+    fa.id_bits = bits;
+    const int S = g.D / 2, PP = g.Pp;
+    size_t lds = inner_fwd_lds(g);
+    const size_t l_fact = (size_t)(4 * PP * PP + 2 * g.F * (S * PP + 16) + g.F * (g.D + 1)) * 4 + 16;
+    size_t l_taps = (size_t)4 * PP * (PP + 4) * 4;
+    const size_t l_red = (size_t)4 * 4 * (PP / 16) * 64 * 16;
+    if (l_red > l_taps) l_taps = l_red;
+    l_taps += 64;
+    if (l_fact > lds) lds = l_fact;
+    if (l_taps > lds) lds = l_taps;
+    if (head_fwd_lds(g) > lds) lds = head_fwd_lds(g);
+    if ((size_t)SMALL_SORT_LDS > lds) lds = SMALL_SORT_LDS;
+    int rc = 0;
+    DISPATCH_NT4(PP / 16, rc = (launch_fwd_all<NT_>(fa, lds, st)));
+    return rc;
 }

@@ -6,169 +6,11 @@
 // (contiguous S*Pp-float rows, 16-byte loads) - HBM/L2-bound and bitwise reproducible (fixed tree).
 #include "internal.hpp"
 
-struct HeadArgs {
-    Geo g;
-    int B;
-    const float* Eo;          // [B,F,D]
-    const float* fb;          // [B,F]
-    const float* inner_out;   // [B]
-    const float* C[CFFM_MAX_LAYERS];
-    const float *d1_w, *d1_b, *d2_w, *d2_b, *att_W, *att_b, *lin_w, *lin_b, *bias;
-    const float* y;           // may be NULL
-    float *t1, *h1, *att, *out, *sqerr;
-    int loss, inner_conv, outer_conv;
-};
+#include "head_body.hpp"
 
-__device__ __forceinline__ float loss_term(float out_raw, float y, int loss, float* out_eval) {
-    switch (loss) {
-        case CFFM_LOSS_MAE: *out_eval = out_raw; return fabsf(y - out_raw);
-        case CFFM_LOSS_LOG: {
-            const float s = 1.f / (1.f + expf(-out_raw));
-            *out_eval = s;                                         // CFFM.py:496
-            return -(y * logf(s + 1e-7f) + (1.f - y) * logf(1.f - s + 1e-7f));
-        }
-        default: *out_eval = out_raw; return (y - out_raw) * (y - out_raw);
-    }
-}
-
-// One workgroup per example.  Everything that does not depend on an earlier phase is loaded first (the
-// embedding tile, this thread's slice of the dense(32) kernel, the first-order inputs), so the kernel pays the
-// L2/HBM latency once instead of once per phase; the pooling sweep keeps four rows in flight per lane.
-#define HEAD_KPP 16      // preloaded dense(32) rows per thread: covers 2D-2 <= 128
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
-    __shared__ float t1s[1024];
-    __shared__ float hpart[8][CFFM_HEAD_UNITS];
-    __shared__ float rs[CFFM_MAX_FIELDS];
-    __shared__ float sc[4];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Et = reinterpret_cast<float*>(smem);                    // [F][D] embedding tile of this example
-    const Geo& g = a.g;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t1w = 2 * g.D - 2;
-    const int q = tid & 31, part = tid >> 5, kpp = (t1w + 7) / 8;
-    // ---- phase 0: independent loads ------------------------------------------------------------------------
-    float w1r[HEAD_KPP];
-    const bool pre = a.outer_conv && kpp <= HEAD_KPP;
-    if (pre) {
-#pragma unroll
-        for (int i = 0; i < HEAD_KPP; ++i) {
-            const int k = part * kpp + i;
-            w1r[i] = (i < kpp && k < t1w) ? a.d1_w[k * CFFM_HEAD_UNITS + q] : 0.f;
-        }
-    }
-    float fbv = 0.f;
-    if (wave == 1 && lane < g.F) fbv = a.fb[(int64_t)b * g.F + lane];
-    if (a.outer_conv) {
-        const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
-        for (int i = tid; i < g.F * g.D / 4; i += 256) reinterpret_cast<float4*>(Et)[i] = E4[i];
-    }
-    float o = 0.f;
-    if (a.outer_conv) {
-        // pools of the live layers: s_{l+1}[y] = sum_{x,q} act(C_l[b,y,x,q])                      (:390-391)
-        int off = g.D;
-        for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
-            const int S = g.D >> (l + 1);
-            const int n4 = S * g.Pp / 4;
-            const float4* base = reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);
-            // wave w owns rows w, w+4, ...; four rows are swept together so that four loads are in flight per lane
-            for (int y0 = wave; y0 < S; y0 += 16) {
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int i = lane; i < n4; i += 64) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int yy = y0 + 4 * u;
-                        if (yy < S) {
-                            const float4 v = base[(int64_t)yy * n4 + i];
-                            s4[u] += (act_pos(v.x, g.act) + act_pos(v.y, g.act)) + (act_pos(v.z, g.act) + act_pos(v.w, g.act));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float t = wave_sum(s4[u]);
-                    if (lane == 0 && y0 + 4 * u < S) t1s[off + y0 + 4 * u] = t;
-                }
-            }
-            off += S;
-        }
-        __syncthreads();                                             // Et (and the pools) are in LDS
-        for (int f = wave; f < g.F; f += 4) {                       // row sums of the embedding tile
-            float s = 0.f;
-            for (int d = lane; d < g.D; d += 64) s += Et[f * g.D + d];
-            s = wave_sum(s);
-            if (lane == 0) rs[f] = s;
-        }
-        __syncthreads();
-        // s0[h] = sum_{w,p} Eo[i_p][h] * Eo[j_p][w] = sum_i Eo[i][h] * sum_{j>i} rowsum(j)   (:381)
-        for (int h = tid; h < g.D; h += 256) {
-            float s = 0.f, R = 0.f;
-            for (int i = g.F - 2; i >= 0; --i) {
-                R += rs[i + 1];
-                s += Et[i * g.D + h] * R;
-            }
-            t1s[h] = s;
-        }
-        __syncthreads();
-        for (int k = tid; k < t1w; k += 256) a.t1[(int64_t)b * t1w + k] = t1s[k];
-        {                                                            // dense(32), :409: 8 partial sums per unit
-            float s = 0.f;
-            if (pre) {
-#pragma unroll
-                for (int i = 0; i < HEAD_KPP; ++i) {
-                    const int k = part * kpp + i;
-                    if (i < kpp && k < t1w) s += t1s[k] * w1r[i];
-                }
-            } else {
-                for (int k = part * kpp; k < min(t1w, (part + 1) * kpp); ++k) s += t1s[k] * a.d1_w[k * CFFM_HEAD_UNITS + q];
-            }
-            hpart[part][q] = s;
-        }
-        __syncthreads();
-        if (wave == 0) {                                             // + bias, then dense(1) * beta, :410, :414
-            float h = 0.f;
-            if (lane < CFFM_HEAD_UNITS) {
-                h = a.d1_b[lane];
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) h += hpart[pp][lane];
-                a.h1[(int64_t)b * CFFM_HEAD_UNITS + lane] = h;
-            }
-            float v = lane < CFFM_HEAD_UNITS ? h * a.d2_w[lane] : 0.f;
-            v = wave_sum(v);
-            if (lane == 0) sc[0] = g.beta_outer * (v + a.d2_b[0]);
-        }
-    }
-    if (wave == 1) {                                                 // first-order term, :422-446
-        float lin;
-        if (g.linear_att) {
-            float z = lane < g.F ? a.att_b[lane] : 0.f;
-            for (int gI = 0; gI < g.F; ++gI) {
-                const float fg = __shfl(fbv, gI, 64);
-                if (lane < g.F) z += fg * a.att_W[gI * g.F + lane];
-            }
-            z = lane < g.F ? z / g.lamda_att : -INFINITY;
-            const float mx = wave_max(z);
-            const float e = lane < g.F ? expf(z - mx) : 0.f;
-            const float den = wave_sum(e);
-            const float at = e / den;
-            if (lane < g.F) a.att[(int64_t)b * g.F + lane] = at;
-            lin = wave_sum(lane < g.F ? fbv * at * a.lin_w[lane] : 0.f) + a.lin_b[0];
-        } else {
-            lin = wave_sum(fbv);
-        }
-        if (lane == 0) sc[1] = lin;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (a.outer_conv) o = sc[0];
-        float out = (a.inner_conv ? a.inner_out[b] : 0.f);
-        out += o;
-        out += sc[1];
-        out += a.bias[0];                                            // :449-453
-        float ev = out;
-        if (a.y) a.sqerr[b] = loss_term(out, a.y[b], a.loss, &ev);
-        else if (a.loss == CFFM_LOSS_LOG) ev = 1.f / (1.f + expf(-out));
-        a.out[b] = ev;
-    }
+    head_fwd_body(a, blockIdx.x, smem);
 }
 
 // deterministic single-workgroup sum of n floats -> dst[0] (and dst[3] when mirror != 0)
@@ -348,7 +190,7 @@ int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     a.t1 = (float*)(w + wl.t1); a.h1 = (float*)(w + wl.h1); a.att = (float*)(w + wl.att);
     a.out = (float*)(w + wl.out); a.sqerr = (float*)(w + wl.sqerr);
     a.loss = s->loss; a.inner_conv = s->inner_conv; a.outer_conv = s->outer_conv;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)s->F * s->D * 4 + 16, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), head_fwd_lds(a.g), (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     if (y && do_sum) {
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)(w + wl.sqerr),

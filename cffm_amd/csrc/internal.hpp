@@ -36,3 +36,7 @@ int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, cons
 // loss-term sum (scalars[0]) to *sum_dst
 int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const float* dEi, const float* dEo, const float* dfb,
                    const float* scalars, float* sum_dst, float* rows, hipStream_t st);
+// whole forward of the fused step in one launch (+ the key sort); only for shapes cffm_fwd_all_ok() accepts
+bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B);
+int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                      const float* y, int32_t B, void* ws, hipStream_t st);

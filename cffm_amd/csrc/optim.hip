@@ -59,53 +59,12 @@ __global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restric
     if (i < n) keys[i] = ((unsigned long long)(unsigned)ids[i * id_stride] << 32) | (unsigned long long)i;
 }
 
-// Single-workgroup stable LSD radix sort (4-bit digits) of up to 4096 packed keys entirely in LDS: one launch
-// instead of rocPRIM's three for the 2560 lookups of a frappe batch.  Thread t owns the contiguous items
-// [t*ipt, (t+1)*ipt), counts its digits in its own column of cnt[16][256] (no atomics), an exclusive scan over
-// (digit-major, thread-minor) gives every (digit, thread) its first output slot, and the thread scatters its items
-// in order - which is what makes the pass stable.
+#include "sort_body.hpp"
+
 __global__ __launch_bounds__(256) void small_sort_kernel(const unsigned long long* __restrict__ in,
                                                          unsigned long long* __restrict__ out, int n, int id_bits) {
-    __shared__ unsigned long long buf[2][4096];
-    __shared__ unsigned short cnt[16 * 256];
-    __shared__ int wtot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < n; i += 256) buf[0][i] = in[i];
-    const int ipt = (n + 255) / 256;
-    const int lo = min(n, tid * ipt), hi = min(n, lo + ipt);
-    int cur = 0;
-    __syncthreads();
-    for (int shift = 32; shift < 32 + id_bits; shift += 4) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) cnt[d * 256 + tid] = 0;
-        for (int i = lo; i < hi; ++i) cnt[(int)((buf[cur][i] >> shift) & 15) * 256 + tid]++;
-        __syncthreads();
-        // exclusive scan of the 4096 counters in linear order; thread t handles entries [16t, 16t+16)
-        int loc[16], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { loc[k] = sum; sum += cnt[16 * tid + k]; }
-        int incl = sum;                                            // inclusive scan across the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        int base = incl - sum;
-        for (int w = 0; w < wave; ++w) base += wtot[w];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cnt[16 * tid + k] = (unsigned short)(base + loc[k]);
-        __syncthreads();
-        for (int i = lo; i < hi; ++i) {
-            const unsigned long long key = buf[cur][i];
-            const int c = (int)((key >> shift) & 15) * 256 + tid;
-            buf[cur ^ 1][cnt[c]++] = key;
-        }
-        cur ^= 1;
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 256) out[i] = buf[cur][i];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    small_sort_body(in, nullptr, out, n, id_bits, smem);
 }
 
 // one wavefront per sorted position; only segment heads do work
@@ -209,7 +168,11 @@ int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_row
         CFFM_CHECK_LAUNCH();
     }
     if (n_rows <= 4096) {                       // one workgroup, one launch
-        hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(256), 0, st, keys_in, keys_out, (int)n_rows, bits);
+        {
+            hipError_t e0 = hipFuncSetAttribute((const void*)small_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_SORT_LDS);
+            if (e0 != hipSuccess) return (int)e0;
+        }
+        hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(256), SMALL_SORT_LDS, st, keys_in, keys_out, (int)n_rows, bits);
         CFFM_CHECK_LAUNCH();
         return 0;
     }
