@@ -6,9 +6,14 @@ OUT   := cffm_amd/lib
 OBJS  := $(patsubst $(SRC)/%.hip,build/%.o,$(wildcard $(SRC)/*.hip))
 CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function -Wno-unused-variable
 
-all: $(OUT)/libcffm_hip.so
+all: $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so
 
-build/%.o: $(SRC)/%.hip $(SRC)/common.hpp include/cffm_hip.h
+# host-only fast libfm reader
+$(OUT)/libcffm_libfm.so: cffm_amd/csrc_host/libfm_reader.cpp
+	@mkdir -p $(OUT)
+	g++ -O2 -std=c++17 -fPIC -shared -Wall $< -o $@
+
+build/%.o: $(SRC)/%.hip $(wildcard $(SRC)/*.hpp) include/cffm_hip.h
 	@mkdir -p build
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
@@ -17,5 +22,5 @@ $(OUT)/libcffm_hip.so: $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
 clean:
-	rm -rf build $(OUT)/libcffm_hip.so
+	rm -rf build $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so
 .PHONY: all clean

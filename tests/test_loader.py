@@ -51,3 +51,49 @@ def test_packed_arrays():
     X, Y = LoadData.packed(d.Train_data)
     assert X.dtype == np.int32 and X.shape == (120, 10) and Y.dtype == np.float32 and Y.shape == (120,)
     assert set(np.unique(Y)) <= {-1.0, 1.0}
+
+
+def _both(path, dataset, loss_type='square_loss'):
+    out = []
+    for native in (False, True):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            d = LoadData(path, dataset, loss_type, native=native)
+        out.append((d, buf.getvalue()))
+    return out
+
+
+def test_native_reader_equals_python_reader_on_golden_slices():
+    (py, out_py), (nat, out_nat) = _both(PATH, 'frappe')
+    assert out_py == out_nat == GOLD['square_loss']['stdout']
+    assert nat.features_M == py.features_M and nat.features == py.features == GOLD['square_loss']['features']
+    for a, b in ((py.Train_data, nat.Train_data), (py.Validation_data, nat.Validation_data), (py.Test_data, nat.Test_data)):
+        assert a['X'] == b['X'] and a['Y'] == b['Y']                 # same rows in the same (argsort) order
+        assert isinstance(b['X'][0], list) and isinstance(b['Y'][0], float)
+
+
+def test_native_reader_on_awkward_text(tmp_path):
+    """Ragged rows, repeated tokens, a token that differs only in its value part, CRLF and trailing spaces,
+    scientific-notation labels, a last line without newline."""
+    d = tmp_path / 'odd'
+    d.mkdir()
+    (d / 'odd.train.libfm').write_text('1 3:1 7:1 3:2\n-1 7:1\r\n0.5 9:1 3:1 11:0.25 \n2e-1 3:1')
+    (d / 'odd.test.libfm').write_text('-1 100:1 3:1\n')
+    (d / 'odd.validation.libfm').write_text('1 7:1 200:1 100:1\n')
+    (py, _), (nat, _) = _both(str(tmp_path) + '/', 'odd')
+    assert py.features == nat.features == {'3:1': 0, '7:1': 1, '3:2': 2, '9:1': 3, '11:0.25': 4, '100:1': 5, '200:1': 6}
+    assert py.features_M == nat.features_M == 7
+    for a, b in ((py.Train_data, nat.Train_data), (py.Validation_data, nat.Validation_data), (py.Test_data, nat.Test_data)):
+        assert sorted(zip(map(tuple, a['X']), a['Y'])) == sorted(zip(map(tuple, b['X']), b['Y']))
+    assert sorted(nat.Train_data['Y']) == [-1.0, 0.2, 0.5, 1.0]
+    assert [len(r) for r in nat.Train_data['X']] == sorted(len(r) for r in nat.Train_data['X'])   # sorted by length
+
+
+def test_native_reader_through_synthetic_generator(tmp_path):
+    from cffm_amd import synth
+    synth.write_libfm(str(tmp_path), 'syn', M=400, F=6, n_train=300, n_valid=80, n_test=50, seed=7)
+    (py, _), (nat, _) = _both(str(tmp_path) + '/', 'syn')
+    assert py.features == nat.features and py.features_M == nat.features_M <= 400
+    assert py.Train_data['X'] == nat.Train_data['X'] and py.Train_data['Y'] == nat.Train_data['Y']
+    X, Y = LoadData.packed(nat.Train_data)
+    assert X.shape == (300, 6) and X.max() < nat.features_M
