@@ -87,6 +87,10 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     out->sort_vals = take(nrows * 8);                            // the same keys, sorted
     out->sort_tmp_bytes = nrows * 32 + (4 << 20);
     out->sort_tmp = take(out->sort_tmp_bytes);
+    if (s->loss == CFFM_LOSS_SQUARE_L2) {                        // dense table gradients of the regularised loss
+        out->Gi = take((int64_t)s->M * s->K * 4);
+        out->Go = take((int64_t)s->M * s->D * 4);
+    }
     out->bytes = o;
     return 0;
 }
@@ -194,6 +198,12 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
     cffm_ws_layout_t wl;
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
+    if (s->loss == CFFM_LOSS_SQUARE_L2) {       // regularised square loss: dense table gradients and updates
+        if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+        if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st))) return rc;
+        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
+        return cffm_tables_adagrad_l2(s, tab, tab_acc, ids, (int64_t)B * s->F, ws, B, st);
+    }
     if (cffm_fwd_all_ok(s, B)) {                 // small-channel shapes: the whole forward (and the key sort) in one launch
         if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st))) return rc;
         if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     const float invB = 1.f / (float)a.Bg;
     float L;
     if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = a.unscaled ? 1.f : sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
+    else if (a.loss == CFFM_LOSS_SQUARE_L2) L = sum;            // data term only (the regularisers are not summed here)
     else L = sum * invB;
     if (blockIdx.x == 0 && tid == 0) {
         a.scalars[1] = L;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
             case CFFM_LOSS_SQUARE_RMSE: d = (out - y) * invB / L; break;
             case CFFM_LOSS_MSE: d = 2.f * (out - y) * invB; break;
             case CFFM_LOSS_MAE: d = (out > y ? 1.f : (out < y ? -1.f : 0.f)) * invB; break;
+            case CFFM_LOSS_SQUARE_L2: d = out - y; break;        // d/dout of sum (y - out)^2 / 2
             default: {
                 const float s = out;   // ws.out holds sigmoid(logit) for log_loss
                 d = -(y / (s + 1e-7f) - (1.f - y) / (1.f - s + 1e-7f)) * invB * s * (1.f - s);

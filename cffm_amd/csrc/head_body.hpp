@@ -18,6 +18,7 @@ struct HeadArgs {
 __device__ __forceinline__ float loss_term(float out_raw, float y, int loss, float* out_eval) {
     switch (loss) {
         case CFFM_LOSS_MAE: *out_eval = out_raw; return fabsf(y - out_raw);
+        case CFFM_LOSS_SQUARE_L2: *out_eval = out_raw; return 0.5f * (y - out_raw) * (y - out_raw);   // tf.nn.l2_loss
         case CFFM_LOSS_LOG: {
             const float s = 1.f / (1.f + expf(-out_raw));
             *out_eval = s;                                         // CFFM.py:496

@@ -40,3 +40,6 @@ int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const f
 bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B);
 int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
                       const float* y, int32_t B, void* ws, hipStream_t st);
+// CFFM_LOSS_SQUARE_L2: tables updated densely with g = scatter(row grads) + lamda * w (feature_bias stays sparse)
+int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, const int32_t* ids,
+                           int64_t n_rows, void* ws, int32_t B_ws, hipStream_t st);

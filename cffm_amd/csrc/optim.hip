@@ -225,3 +225,76 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
     return cffm_sparse_apply_strided(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws,
                                      B_ws, ls, st);
 }
+
+// ---- regularised square loss (CFFM.py:489-491): the l2 terms make the table gradients dense ------------------------
+// 1) segment heads of the sorted keys write the duplicates-summed row gradients into zeroed dense buffers Gi/Go and
+//    apply the (still sparse) feature_bias update; 2) a dense sweep applies Adagrad with g = G + lamda * w to every row.
+__global__ __launch_bounds__(256) void scatter_rows_l2_kernel(const unsigned long long* __restrict__ keys, int64_t n, int M,
+                                                              int K, int D, const float* __restrict__ dEi,
+                                                              const float* __restrict__ dEo, const float* __restrict__ dfb,
+                                                              float* __restrict__ Gi, float* __restrict__ Go,
+                                                              float* __restrict__ fbias, float* __restrict__ a_fbias, float lr) {
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pos >= n) return;
+    const int id = (int)(keys[pos] >> 32);
+    if (pos > 0 && (int)(keys[pos - 1] >> 32) == id) return;
+    if (id < 0 || id >= M) return;
+    const int W = K + D + 1;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= W) continue;
+        float g = 0.f;
+        for (int64_t q = pos; q < n; ++q) {
+            const unsigned long long kq = keys[q];
+            if ((int)(kq >> 32) != id) break;
+            const int64_t sl = (int64_t)(kq & 0xffffffffull);
+            g += c < K ? dEi[sl * K + c] : (c < K + D ? dEo[sl * D + (c - K)] : dfb[sl]);
+        }
+        if (c < K) Gi[(int64_t)id * K + c] = g;
+        else if (c < K + D) Go[(int64_t)id * D + (c - K)] = g;
+        else {
+            const float a = a_fbias[id] + g * g;
+            a_fbias[id] = a;
+            fbias[id] -= lr * g / sqrtf(a);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void table_adagrad_l2_kernel(float* __restrict__ w, float* __restrict__ acc,
+                                                               const float* __restrict__ G, int64_t n, float lam, float lr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = G[i] + lam * w[i];
+    const float a = acc[i] + g * g;
+    acc[i] = a;
+    w[i] -= lr * g / sqrtf(a);
+}
+
+int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, const int32_t* ids,
+                           int64_t n_rows, void* ws, int32_t B_ws, hipStream_t st) {
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B_ws, &wl);
+    char* w = (char*)ws;
+    float* Gi = (float*)(w + wl.Gi);
+    float* Go = (float*)(w + wl.Go);
+    const int64_t ni = (int64_t)s->M * s->K, no = (int64_t)s->M * s->D;
+    hipError_t e = hipMemsetAsync(Gi, 0, (size_t)ni * 4, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(Go, 0, (size_t)no * 4, st);
+    if (e != hipSuccess) return (int)e;
+    int rc = cffm_sort_keys_impl(s, ids, n_rows, ws, B_ws, true, st);
+    if (rc) return rc;
+    const unsigned long long* keys = (const unsigned long long*)(w + wl.sort_vals);
+    hipLaunchKernelGGL(scatter_rows_l2_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys, n_rows, s->M, s->K,
+                       s->D, (const float*)(w + wl.dEi), (const float*)(w + wl.dEo), (const float*)(w + wl.dfb), Gi, Go,
+                       tab->feat_bias, acc->feat_bias, s->lr);
+    CFFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(table_adagrad_l2_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, st, tab->inner_emb,
+                       acc->inner_emb, Gi, ni, s->lamda, s->lr);
+    CFFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(table_adagrad_l2_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, tab->outer_emb,
+                       acc->outer_emb, Go, no, s->lamda_att, s->lr);       // quirk Q13: lamda_att scales the outer table
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

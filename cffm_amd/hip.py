@@ -17,7 +17,8 @@ LOSS_IDS = {'square_loss': 0, 'mse': 1, 'mae': 2, 'log_loss': 3}
 class Shape(C.Structure):
     _fields_ = [('M', C.c_int32), ('F', C.c_int32), ('K', C.c_int32), ('D', C.c_int32), ('act', C.c_int32),
                 ('linear_att', C.c_int32), ('inner_conv', C.c_int32), ('outer_conv', C.c_int32),
-                ('loss', C.c_int32), ('lamda_att', C.c_float), ('beta_outer', C.c_float), ('lr', C.c_float)]
+                ('loss', C.c_int32), ('lamda_att', C.c_float), ('beta_outer', C.c_float), ('lr', C.c_float),
+                ('lamda', C.c_float)]
 
 
 class ThetaLayout(C.Structure):
@@ -36,7 +37,7 @@ class WsLayout(C.Structure):
                 ('sqerr', C.c_int64), ('scalars', C.c_int64), ('dout', C.c_int64), ('dt1', C.c_int64),
                 ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
                 ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
-                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64)]
+                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64)]
 
 
 class Tables(C.Structure):
@@ -91,7 +92,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.cffm_abi_version() != 1:
+    if lib.cffm_abi_version() != 2:
         raise RuntimeError('cffm_amd: ABI version mismatch')
     _lib = lib
     return lib
@@ -106,11 +107,13 @@ def check(rc):
 def make_shape(cfg):
     if cfg.loss_type not in LOSS_IDS:
         raise ValueError('loss_type %r is not supported by the HIP path' % (cfg.loss_type,))
+    loss = LOSS_IDS[cfg.loss_type]
     if cfg.loss_type == 'square_loss' and cfg.lamda_bilinear > 0:
-        raise ValueError('square_loss with lamda > 0 is not supported by the HIP path yet')
+        loss = 4                                    # CFFM_LOSS_SQUARE_L2
     return Shape(M=cfg.M, F=cfg.F, K=cfg.K, D=cfg.D, act=cfg.act_id, linear_att=cfg.linear_att,
-                 inner_conv=cfg.inner_conv, outer_conv=cfg.outer_conv, loss=LOSS_IDS[cfg.loss_type],
-                 lamda_att=cfg.lamda_att, beta_outer=float(cfg.beta_outer), lr=cfg.lr)
+                 inner_conv=cfg.inner_conv, outer_conv=cfg.outer_conv, loss=loss,
+                 lamda_att=cfg.lamda_att, beta_outer=float(cfg.beta_outer), lr=cfg.lr,
+                 lamda=float(cfg.lamda_bilinear))
 
 
 def theta_layout(shape):

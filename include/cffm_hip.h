@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 1
+#define CFFM_ABI_VERSION 2
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -40,7 +40,8 @@ extern "C" {
 /* activation ids, CFFM.py:132-141 */
 enum { CFFM_ACT_RELU = 0, CFFM_ACT_PRELU = 1, CFFM_ACT_ELU = 2, CFFM_ACT_SELU = 3, CFFM_ACT_GELU = 4 };
 /* loss ids, CFFM.py:486-514 (square_loss with lamda == 0 is the README default) */
-enum { CFFM_LOSS_SQUARE_RMSE = 0, CFFM_LOSS_MSE = 1, CFFM_LOSS_MAE = 2, CFFM_LOSS_LOG = 3 };
+enum { CFFM_LOSS_SQUARE_RMSE = 0, CFFM_LOSS_MSE = 1, CFFM_LOSS_MAE = 2, CFFM_LOSS_LOG = 3,
+       CFFM_LOSS_SQUARE_L2 = 4 /* square_loss with lamda > 0: l2_loss + table regularisers, CFFM.py:489-491 */ };
 
 typedef struct cffm_shape {
     int32_t M;            /* features_M                                   CFFM.py:110            */
@@ -55,6 +56,7 @@ typedef struct cffm_shape {
     float lamda_att;      /* CFFM.py:434                                                         */
     float beta_outer;     /* CFFM.py:414                                                         */
     float lr;             /* CFFM.py:523                                                         */
+    float lamda;          /* lamda_bilinear, only used by CFFM_LOSS_SQUARE_L2    CFFM.py:489-491          */
 } cffm_shape_t;
 
 /* Offsets (in floats) of the trained dense parameters inside ONE flat fp32 buffer "theta".  The same
@@ -93,6 +95,7 @@ typedef struct cffm_ws_layout {
     int64_t sort_keys, sort_vals;           /* int32 [B*F] each (sorted ids, source slots)         */
     int64_t sort_tmp;                       /* radix sort scratch                                  */
     int64_t sort_tmp_bytes;
+    int64_t Gi, Go;                         /* CFFM_LOSS_SQUARE_L2 only: dense table gradients [M,K], [M,D]   */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */

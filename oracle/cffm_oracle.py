@@ -397,6 +397,18 @@ def train_step(p, acc, X, y, cfg, cache_hook=None):
         else:
             adagrad_dense(p[name], acc[name], grad.reshape(p[name].shape), lr)
     ids = np.asarray(X).reshape(-1)
+    lam = getattr(cfg, 'lamda_bilinear', 0.0)
+    if cfg.loss_type == 'square_loss' and lam > 0:
+        # CFFM.py:489-491: the l2_regularizer terms make the table gradients DENSE (IndexedSlices + dense is
+        # aggregated to a dense tensor by TF), so Adagrad updates every row and every accumulator; the outer
+        # table is scaled by lamda_att (quirk Q13)
+        for name, key, scale in (('inner_embeddings', 'd_inner_rows', lam), ('outer_embeddings', 'd_outer_rows', cfg.lamda_att)):
+            if key in g:
+                dense = scale * p[name]
+                np.add.at(dense, ids, g[key].reshape(ids.shape[0], -1))
+                adagrad_dense(p[name], acc[name], dense, lr)
+        adagrad_sparse(p['feature_bias'], acc['feature_bias'], ids, g['d_bias_rows'], lr)
+        return L, out
     if 'd_inner_rows' in g:
         adagrad_sparse(p['inner_embeddings'], acc['inner_embeddings'], ids, g['d_inner_rows'], lr)
     if 'd_outer_rows' in g:

@@ -355,3 +355,44 @@ def test_data_parallel_halves_on_one_gpu():
             u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
             extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
+
+
+def test_regularised_square_loss_step():
+    """--lamda > 0 (CFFM.py:489-491): l2_loss data term, dense table gradients scatter(row grads) + lamda * w with
+    the outer table scaled by lamda_att (Q13), dense Adagrad over both tables, sparse feature_bias."""
+    cfg, p32, X, y = make_case('bookx-relu')
+    cfg.lamda_bilinear = 0.02
+    eng = engine_for(cfg, p32)
+    p64 = to64(p32)
+    B = X.shape[0]
+    eng.forward(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    hook = lambda cache: adopt_device_kinks(cfg, eng, B, cache)
+    out, c = orc.forward(p64, X, cfg)
+    hook(c)
+    _, dout = orc.loss_and_grad(out, y.astype(np.float64), cfg, p64)
+    g = orc.backward(p64, c, dout, cfg)
+    ids = X.reshape(-1)
+    dense = {}
+    for name, key, scale in (('inner_embeddings', 'd_inner_rows', cfg.lamda_bilinear), ('outer_embeddings', 'd_outer_rows', cfg.lamda_att)):
+        t = scale * p64[name]
+        np.add.at(t, ids, g[key].reshape(ids.shape[0], -1))
+        dense[name] = t
+    acc = orc.init_accumulators(p64)
+    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg, cache_hook=hook)
+    loss = eng.train_step(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    data_term = 0.5 * np.sum((y.astype(np.float64) - out) ** 2)
+    close(loss.cpu().numpy(), [data_term], 'loss (data term)')
+    got, gacc = eng.export_params(), eng.export_accumulators()
+    for k in ('inner_embeddings', 'outer_embeddings'):
+        gk = dense[k]
+        dg = 1e-5 * np.abs(gk).max()
+        u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
+        extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
+        close(got[k], p64[k], 'param ' + k, tol=2e-5, extra=extra)
+        close(gacc[k], acc[k], 'acc ' + k, tol=2e-5, extra=2 * np.abs(gk) * dg + dg * dg)
+        assert (gacc[k] > 1e-8).mean() > 0.99           # every row was updated
+    touched = np.zeros(cfg.M, dtype=bool)
+    touched[ids] = True
+    np.testing.assert_array_equal(got['feature_bias'][~touched], p32['feature_bias'][~touched])

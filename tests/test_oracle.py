@@ -191,3 +191,25 @@ def test_conv0_rank1_factorisation():
             for pidx, (i, j) in enumerate(zip(ii, jj)):
                 fact += (E[i, dh::2][:, None, None] * E[j, dw::2][None, :, None]) * W[dh, dw, pidx][None, None, :]
     np.testing.assert_allclose(direct, fact, rtol=1e-12, atol=1e-13)
+
+
+def test_regularised_square_loss_step_matches_twin():
+    """lamda > 0 (CFFM.py:489-491): the l2 terms make the table gradients dense, so every row and accumulator of
+    the inner/outer tables moves; the outer table is scaled by lamda_att (quirk Q13)."""
+    cfg, p, X, y = _setup(CASES[1])
+    cfg.lamda_bilinear = 0.03
+    p0 = {k: v.copy() for k, v in p.items()}
+    acc = orc.init_accumulators(p)
+    L, _ = orc.train_step(p, acc, X, y, cfg)
+    tp = _torch_params(p0)
+    tL = twin.loss(twin.forward(tp, torch.tensor(X), cfg), torch.tensor(y), cfg, tp)
+    tL.backward()
+    assert abs(L - tL.item()) < 1e-10
+    for name in ('inner_embeddings', 'outer_embeddings', 'feature_bias', 'dense_1_kernel', 'outer_layer_conv_weight_0', 'bias_W'):
+        gr = tp[name].grad.numpy()
+        want = p0[name] - cfg.lr * gr / np.sqrt(1e-8 + gr * gr)
+        np.testing.assert_allclose(p[name], want, rtol=1e-9, atol=1e-12, err_msg=name)
+    untouched = np.ones(cfg.M, dtype=bool)
+    untouched[X.reshape(-1)] = False
+    assert (p['inner_embeddings'][untouched] != p0['inner_embeddings'][untouched]).any()      # dense update
+    np.testing.assert_array_equal(p['feature_bias'][untouched], p0['feature_bias'][untouched])  # still sparse

@@ -71,9 +71,13 @@ def forward(p, X, cfg):
     return sum(parts).reshape(B)
 
 
-def loss(out, y, cfg):
+def loss(out, y, cfg, p=None):
     if cfg.loss_type == 'square_loss' and not cfg.lamda_bilinear > 0:
         return torch.sqrt(torch.mean((y - out) ** 2) + 1e-10)
+    if cfg.loss_type == 'square_loss':
+        # tf.nn.l2_loss(t) = sum(t^2)/2; l2_regularizer(s)(w) = s * l2_loss(w)   (CFFM.py:489-491)
+        return 0.5 * torch.sum((y - out) ** 2) + cfg.lamda_bilinear * 0.5 * torch.sum(p['inner_embeddings'] ** 2) \
+            + cfg.lamda_att * 0.5 * torch.sum(p['outer_embeddings'] ** 2)
     if cfg.loss_type == 'mse':
         return torch.mean((y - out) ** 2)
     if cfg.loss_type == 'mae':
