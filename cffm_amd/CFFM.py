@@ -15,6 +15,7 @@ same log line formats (CFFM.py:174-179, :218-221, :553, :658-664, :684-695).  Wh
   a warning, ``--pretrain 1`` (Q7) restores THIS model's tensors, no CUDA_VISIBLE_DEVICES pin (Q8).
 """
 import argparse
+import ast
 import logging
 import math
 import os
@@ -104,14 +105,17 @@ class CFFM(object):
         self.beta_outer = beta_outer
         self.num_interactions = int(self.num_field * (self.num_field - 1) / 2)
         self.activation_function = activation_function
-        if optimizer_type != 'AdagradOptimizer':
-            raise NotImplementedError('only AdagradOptimizer (the reference default, CFFM.py:48) runs on the HIP path')
+        if optimizer_type not in ('AdagradOptimizer', 'AdamOptimizer', 'GradientDescentOptimizer', 'MomentumOptimizer'):
+            # the reference leaves self.optimizer unset for any other string and dies at the first sess.run (CFFM.py:517-529)
+            raise ValueError('unknown optimizer %r' % (optimizer_type,))
+        if optimizer_type != 'AdagradOptimizer' and lamda_bilinear > 0:
+            raise NotImplementedError('lamda > 0 is built for AdagradOptimizer only (the reference default)')
         if tensorboard > 0:
             logging.warning('--tensorboard is accepted and ignored (it crashes the reference, CFFM.py:194-196)')
         self.config = CFFMConfig(M=features_M, F=num_field, K=inner_dims, D=outer_dims, activation=activation_function,
                                  lamda_att=lamda_att, beta_outer=beta_outer, linear_att=linear_att,
                                  inner_conv=inner_conv, outer_conv=outer_conv, loss_type=loss_type,
-                                 lamda_bilinear=lamda_bilinear, lr=learning_rate)
+                                 lamda_bilinear=lamda_bilinear, lr=learning_rate, optimizer=optimizer_type)
         self.create_save_folder(save_file)
         self.train_rmse, self.valid_rmse, self.test_rmse = [], [], []
         self.train_r2, self.valid_r2, self.test_r2 = [], [], []
@@ -263,12 +267,15 @@ class CFFM(object):
     def save(self, save_file):
         import torch
         torch.save({'config': self.config.__dict__, 'params': self.engine.export_params(),
-                    'accumulators': self.engine.export_accumulators()}, save_file + '.pt')
+                    'accumulators': self.engine.export_accumulators(),
+                    'second_moments': self.engine.export_second_moments(), 'opt_step': self.engine.opt_step},
+                   save_file + '.pt')
 
     def load(self, save_file):
         import torch
         blob = torch.load(save_file + '.pt', weights_only=False)
-        self.engine.load_params(blob['params'], blob['accumulators'])
+        self.engine.load_params(blob['params'], blob['accumulators'], blob.get('second_moments'))
+        self.engine.opt_step = int(blob.get('opt_step', 0))
 
 
 def main(argv=None):
@@ -280,13 +287,13 @@ def main(argv=None):
             ", batch_norm=%d, num_field=%d, linear_att=%d, att_dim=%d,lamda_att=%.2f,inner_conv=%d,gamma_inner=%.1f,"
             "outer_conv=%d,beta_outer=%.1f, activation=%s"
             % (args.dataset, args.inner_dims, args.loss_type, args.epoch, args.batch_size, args.lr, args.lamda,
-               eval(args.keep), args.optimizer, args.batch_norm, args.num_field, args.linear_att, args.att_dim,
+               ast.literal_eval(args.keep), args.optimizer, args.batch_norm, args.num_field, args.linear_att, args.att_dim,
                args.lamda_att, args.inner_conv, args.gamma_inner, args.outer_conv, args.beta_outer, args.activation))
     data = DATA.LoadData(args.path, args.dataset, args.loss_type)
     save_file = 'pretrain/CFFM/%s_%d/%s_%d' % (args.dataset, args.inner_dims, args.dataset, args.inner_dims)
     t1 = time()
     cf_fm = CFFM(data.features_M, args.pretrain, save_file, args.inner_dims, args.outer_dims, args.loss_type,
-                 args.epoch, args.batch_size, args.lr, args.lamda, eval(args.keep), args.optimizer, args.batch_norm,
+                 args.epoch, args.batch_size, args.lr, args.lamda, ast.literal_eval(args.keep), args.optimizer, args.batch_norm,
                  args.verbose, args.tensorboard, args.num_field, args.linear_att, args.att_dim, args.lamda_att,
                  args.inner_conv, args.gamma_inner, args.outer_conv, args.beta_outer, args.activation)
     cf_fm.train(data)

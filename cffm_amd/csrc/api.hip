@@ -87,9 +87,10 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     out->sort_vals = take(nrows * 8);                            // the same keys, sorted
     out->sort_tmp_bytes = nrows * 32 + (4 << 20);
     out->sort_tmp = take(out->sort_tmp_bytes);
-    if (s->loss == CFFM_LOSS_SQUARE_L2) {                        // dense table gradients of the regularised loss
+    if (s->loss == CFFM_LOSS_SQUARE_L2 || s->optimizer == CFFM_OPT_ADAM) {   // dense table gradients
         out->Gi = take((int64_t)s->M * s->K * 4);
         out->Go = take((int64_t)s->M * s->D * 4);
+        out->Gfb = take((int64_t)s->M * 4);
     }
     out->bytes = o;
     return 0;
@@ -155,7 +156,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
         hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)wl.gpart_floats * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
-    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused, loss_out, stream, unscaled))) return rc;
+    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, stream, unscaled))) return rc;
     if (s->outer_conv) {
         for (int l = g.live - 1; l >= 1; --l)
             if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
@@ -217,4 +218,22 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
                                     s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
                                     s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),
                                     ws, B, true, st);
+}
+
+extern "C" int cffm_train_step_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_state1,
+                                   const cffm_tables_t* tab_state2, float* theta, float* theta_state1, float* theta_state2,
+                                   float* grad, const int32_t* ids, const float* y, int32_t B, void* ws, float* loss,
+                                   int64_t step, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (s->optimizer == CFFM_OPT_ADAGRAD)
+        return cffm_train_step(s, tab, tab_state1, theta, theta_state1, grad, ids, y, B, ws, loss, stream);
+    if (B <= 0) return 0;
+    if (s->loss == CFFM_LOSS_SQUARE_L2 || !s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st))) return rc;
+    // gradients only (no fused Adagrad); the loss is written by head_bwd
+    if ((rc = backward_impl(s, theta, nullptr, y, B, (int64_t)B, ws, grad, false, loss, st))) return rc;
+    return cffm_apply_opt(s, tab, tab_state1, tab_state2, theta, theta_state1, theta_state2, grad, ids, (int64_t)B * s->F, ws,
+                          B, step, st);
 }

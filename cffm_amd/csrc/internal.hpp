@@ -43,3 +43,7 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
 // CFFM_LOSS_SQUARE_L2: tables updated densely with g = scatter(row grads) + lamda * w (feature_bias stays sparse)
 int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, const int32_t* ids,
                            int64_t n_rows, void* ws, int32_t B_ws, hipStream_t st);
+// SGD / Momentum / Adam updates of theta and the three tables from grad + the row gradients in ws (CFFM.py:519-529)
+int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* st1, const cffm_tables_t* st2,
+                   float* theta, float* th1, float* th2, const float* grad, const int32_t* ids, int64_t n_rows, void* ws,
+                   int32_t B_ws, int64_t step, hipStream_t st);

@@ -8,6 +8,7 @@
 //                   its segment in slot order - HBM-bound: per distinct row 5 x (K+D+1) x 4 bytes.
 #include "internal.hpp"
 
+#include <cmath>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -296,5 +297,107 @@ int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, cons
     hipLaunchKernelGGL(table_adagrad_l2_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, tab->outer_emb,
                        acc->outer_emb, Go, no, s->lamda_att, s->lr);       // quirk Q13: lamda_att scales the outer table
     CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the other optimizers of CFFM.py:519-529 (TF-1.14 semantics) ------------------------------------------------------
+struct OptConst { int opt; float lr, lr_t, b1, b2, omb1, omb2, eps, mom; };   // omb* = 1 - beta, rounded once from double
+
+__device__ __forceinline__ void opt_update(float& w, float* s1, float* s2, float g, const OptConst& c) {
+    if (c.opt == CFFM_OPT_SGD) {
+        w -= c.lr * g;
+    } else if (c.opt == CFFM_OPT_MOMENTUM) {
+        const float a = c.mom * (*s1) + g;
+        *s1 = a;
+        w -= c.lr * a;
+    } else {                                      // Adam
+        const float m = c.b1 * (*s1) + c.omb1 * g;
+        const float v = c.b2 * (*s2) + c.omb2 * g * g;
+        *s1 = m; *s2 = v;
+        w -= c.lr_t * m / (sqrtf(v) + c.eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, float* __restrict__ s1, float* __restrict__ s2,
+                                                        const float* __restrict__ grad, int64_t n, OptConst c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float wv = w[i];
+    opt_update(wv, s1 ? s1 + i : nullptr, s2 ? s2 + i : nullptr, grad ? grad[i] : 0.f, c);
+    w[i] = wv;
+}
+
+// SGD / Momentum on the touched rows (duplicates summed first, in slot order); Adam: the summed rows go to the dense
+// buffers G* and dense_opt_kernel then sweeps every row (TF's non-lazy sparse Adam moves all of them)
+__global__ __launch_bounds__(256) void sparse_opt_kernel(const unsigned long long* __restrict__ keys, int64_t n, int M, int K, int D,
+                                                         const float* __restrict__ dEi, const float* __restrict__ dEo,
+                                                         const float* __restrict__ dfb, cffm_tables_t tab, cffm_tables_t st1,
+                                                         float* __restrict__ Gi, float* __restrict__ Go, float* __restrict__ Gfb,
+                                                         OptConst c) {
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pos >= n) return;
+    const int id = (int)(keys[pos] >> 32);
+    if (pos > 0 && (int)(keys[pos - 1] >> 32) == id) return;
+    if (id < 0 || id >= M) return;
+    const int W = K + D + 1;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int col = c0 + lane;
+        if (col >= W) continue;
+        float g = 0.f;
+        for (int64_t q = pos; q < n; ++q) {
+            const unsigned long long kq = keys[q];
+            if ((int)(kq >> 32) != id) break;
+            const int64_t sl = (int64_t)(kq & 0xffffffffull);
+            g += col < K ? dEi[sl * K + col] : (col < K + D ? dEo[sl * D + (col - K)] : dfb[sl]);
+        }
+        const int64_t off = col < K ? (int64_t)id * K + col : (col < K + D ? (int64_t)id * D + (col - K) : (int64_t)id);
+        float* wt = col < K ? tab.inner_emb : (col < K + D ? tab.outer_emb : tab.feat_bias);
+        if (c.opt == CFFM_OPT_ADAM) {
+            (col < K ? Gi : (col < K + D ? Go : Gfb))[off] = g;
+        } else {
+            float* s1 = c.opt == CFFM_OPT_MOMENTUM ? (col < K ? st1.inner_emb : (col < K + D ? st1.outer_emb : st1.feat_bias)) + off : nullptr;
+            float wv = wt[off];
+            opt_update(wv, s1, nullptr, g, c);
+            wt[off] = wv;
+        }
+    }
+}
+
+int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* st1, const cffm_tables_t* st2,
+                   float* theta, float* th1, float* th2, const float* grad, const int32_t* ids, int64_t n_rows, void* ws,
+                   int32_t B_ws, int64_t step, hipStream_t st) {
+    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
+    cffm_ws_layout(s, B_ws, &wl); cffm_theta_layout(s, &tl);
+    char* w = (char*)ws;
+    OptConst c;
+    c.opt = s->optimizer; c.lr = s->lr; c.b1 = 0.9f; c.b2 = 0.999f; c.omb1 = (float)(1.0 - 0.9); c.omb2 = (float)(1.0 - 0.999); c.eps = 1e-8f; c.mom = 0.95f;
+    c.lr_t = (float)((double)s->lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step)));
+    hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, st, theta, th1, th2, grad,
+                       (int64_t)tl.n, c);
+    CFFM_CHECK_LAUNCH();
+    float *Gi = nullptr, *Go = nullptr, *Gfb = nullptr;
+    const int64_t ni = (int64_t)s->M * s->K, no = (int64_t)s->M * s->D, nf = s->M;
+    if (c.opt == CFFM_OPT_ADAM) {
+        Gi = (float*)(w + wl.Gi); Go = (float*)(w + wl.Go); Gfb = (float*)(w + wl.Gfb);
+        hipError_t e = hipMemsetAsync(Gi, 0, (size_t)(wl.Gfb + nf * 4 - wl.Gi), st);     // the three buffers are contiguous
+        if (e != hipSuccess) return (int)e;
+    }
+    int rc = cffm_sort_keys_impl(s, ids, n_rows, ws, B_ws, true, st);
+    if (rc) return rc;
+    cffm_tables_t t1 = st1 ? *st1 : cffm_tables_t{nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(sparse_opt_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
+                       (const unsigned long long*)(w + wl.sort_vals), n_rows, s->M, s->K, s->D, (const float*)(w + wl.dEi),
+                       (const float*)(w + wl.dEo), (const float*)(w + wl.dfb), *tab, t1, Gi, Go, Gfb, c);
+    CFFM_CHECK_LAUNCH();
+    if (c.opt == CFFM_OPT_ADAM) {
+        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, st, tab->inner_emb, st1->inner_emb,
+                           st2->inner_emb, (const float*)Gi, ni, c);
+        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, tab->outer_emb, st1->outer_emb,
+                           st2->outer_emb, (const float*)Go, no, c);
+        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, tab->feat_bias, st1->feat_bias,
+                           st2->feat_bias, (const float*)Gfb, nf, c);
+        CFFM_CHECK_LAUNCH();
+    }
     return 0;
 }

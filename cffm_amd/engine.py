@@ -44,16 +44,26 @@ class HipEngine(object):
         n = int(self.tl.n)
         dev = self.device
         self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.theta_acc = torch.full((n,), ADAGRAD_INIT_ACC, dtype=torch.float32, device=dev)
+        # optimizer slots (CFFM.py:517-529): Adagrad accumulators start at 1e-8, Momentum accumulators / Adam m, v at 0
+        acc0 = ADAGRAD_INIT_ACC if cfg.optimizer == 'AdagradOptimizer' else 0.0
+        self.acc0 = acc0
+        self.theta_acc = torch.full((n,), acc0, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n + 4, dtype=torch.float32, device=dev)[:n]      # +4: loss-sum slot of the DP step
         self._grad_full = self.grad._base if self.grad._base is not None else self.grad
         M = cfg.M
         self.inner = torch.zeros((M, cfg.K), dtype=torch.float32, device=dev)
         self.outer = torch.zeros((M, cfg.D), dtype=torch.float32, device=dev)
         self.fbias = torch.zeros((M,), dtype=torch.float32, device=dev)
-        self.inner_acc = torch.full_like(self.inner, ADAGRAD_INIT_ACC)
-        self.outer_acc = torch.full_like(self.outer, ADAGRAD_INIT_ACC)
-        self.fbias_acc = torch.full_like(self.fbias, ADAGRAD_INIT_ACC)
+        self.inner_acc = torch.full_like(self.inner, acc0)
+        self.outer_acc = torch.full_like(self.outer, acc0)
+        self.fbias_acc = torch.full_like(self.fbias, acc0)
+        self.opt_step = 0
+        self.theta_acc2 = self.tables_acc2 = None
+        if cfg.optimizer == 'AdamOptimizer':                         # second moment
+            self.theta_acc2 = torch.zeros_like(self.theta_acc)
+            self.inner_acc2, self.outer_acc2 = torch.zeros_like(self.inner), torch.zeros_like(self.outer)
+            self.fbias_acc2 = torch.zeros_like(self.fbias)
+            self.tables_acc2 = hip.Tables(self.inner_acc2.data_ptr(), self.outer_acc2.data_ptr(), self.fbias_acc2.data_ptr())
         self.tables = hip.Tables(self.inner.data_ptr(), self.outer.data_ptr(), self.fbias.data_ptr())
         self.tables_acc = hip.Tables(self.inner_acc.data_ptr(), self.outer_acc.data_ptr(), self.fbias_acc.data_ptr())
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -90,7 +100,7 @@ class HipEngine(object):
         n = int(np.prod(shp)) if shp else 1
         return flat[off:off + n].reshape(shp).copy()
 
-    def load_params(self, params, accs=None):
+    def load_params(self, params, accs=None, accs2=None):
         shapes = param_shapes(self.cfg)
         host = np.zeros(int(self.tl.n), dtype=np.float32)
         for off, name in self._members():
@@ -103,16 +113,25 @@ class HipEngine(object):
         trained = set(n for _, n in self._members()) | {'inner_embeddings', 'outer_embeddings', 'feature_bias'}
         self._host_only = {k: np.array(params[k], dtype=np.float32) for k in shapes if k not in trained}
         if accs is not None:
-            ha = np.full(int(self.tl.n), ADAGRAD_INIT_ACC, dtype=np.float32)
+            ha = np.full(int(self.tl.n), self.acc0, dtype=np.float32)
             for off, name in self._members():
                 v = self._pack(name, accs[name])
                 if name.startswith('outer_layer_conv_'):
-                    v = np.where(v == 0, np.float32(ADAGRAD_INIT_ACC), v)     # pads keep the initial accumulator
+                    v = np.where(v == 0, np.float32(self.acc0), v)     # pads keep the initial accumulator
                 ha[off:off + v.size] = v
             self.theta_acc.copy_(torch.from_numpy(ha))
             self.inner_acc.copy_(torch.from_numpy(np.asarray(accs['inner_embeddings'], dtype=np.float32)))
             self.outer_acc.copy_(torch.from_numpy(np.asarray(accs['outer_embeddings'], dtype=np.float32)))
             self.fbias_acc.copy_(torch.from_numpy(np.asarray(accs['feature_bias'], dtype=np.float32).reshape(-1)))
+        if accs2 is not None and self.theta_acc2 is not None:
+            h2 = np.zeros(int(self.tl.n), dtype=np.float32)
+            for off, name in self._members():
+                v = self._pack(name, accs2[name])
+                h2[off:off + v.size] = v
+            self.theta_acc2.copy_(torch.from_numpy(h2))
+            self.inner_acc2.copy_(torch.from_numpy(np.asarray(accs2['inner_embeddings'], dtype=np.float32)))
+            self.outer_acc2.copy_(torch.from_numpy(np.asarray(accs2['outer_embeddings'], dtype=np.float32)))
+            self.fbias_acc2.copy_(torch.from_numpy(np.asarray(accs2['feature_bias'], dtype=np.float32).reshape(-1)))
 
     def _export(self, flat, inner, outer, fbias):
         shapes = param_shapes(self.cfg)
@@ -132,6 +151,12 @@ class HipEngine(object):
 
     def export_accumulators(self):
         return self._export(self.theta_acc, self.inner_acc, self.outer_acc, self.fbias_acc)
+
+    def export_second_moments(self):
+        """Adam's v slots (None for the other optimizers)."""
+        if self.theta_acc2 is None:
+            return None
+        return self._export(self.theta_acc2, self.inner_acc2, self.outer_acc2, self.fbias_acc2)
 
     def export_grad(self):
         """Dense-parameter gradients of the last backward, by reference variable name."""
@@ -193,6 +218,14 @@ class HipEngine(object):
             y = y.to(torch.float32).contiguous()
         B = ids.shape[0]
         buf, _ = self.workspace(B)
+        if self.cfg.optimizer != 'AdagradOptimizer':
+            self.opt_step += 1
+            hip.check(self.lib.cffm_train_step_opt(
+                C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+                C.byref(self.tables_acc2) if self.tables_acc2 is not None else None, _ptr(self.theta),
+                _ptr(self.theta_acc), _ptr(self.theta_acc2), _ptr(self.grad), _ptr(ids), _ptr(y), B, _ptr(buf),
+                _ptr(self.loss_buf), self.opt_step, self._stream()))
+            return self.loss_buf
         hip.check(self.lib.cffm_train_step(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
                                            _ptr(self.theta), _ptr(self.theta_acc), _ptr(self.grad), _ptr(ids),
                                            _ptr(y), B, _ptr(buf), _ptr(self.loss_buf), self._stream()))

@@ -12,13 +12,14 @@ MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
 LOSS_IDS = {'square_loss': 0, 'mse': 1, 'mae': 2, 'log_loss': 3}
+OPT_IDS = {'AdagradOptimizer': 0, 'GradientDescentOptimizer': 1, 'MomentumOptimizer': 2, 'AdamOptimizer': 3}
 
 
 class Shape(C.Structure):
     _fields_ = [('M', C.c_int32), ('F', C.c_int32), ('K', C.c_int32), ('D', C.c_int32), ('act', C.c_int32),
                 ('linear_att', C.c_int32), ('inner_conv', C.c_int32), ('outer_conv', C.c_int32),
                 ('loss', C.c_int32), ('lamda_att', C.c_float), ('beta_outer', C.c_float), ('lr', C.c_float),
-                ('lamda', C.c_float)]
+                ('lamda', C.c_float), ('optimizer', C.c_int32)]
 
 
 class ThetaLayout(C.Structure):
@@ -37,7 +38,7 @@ class WsLayout(C.Structure):
                 ('sqerr', C.c_int64), ('scalars', C.c_int64), ('dout', C.c_int64), ('dt1', C.c_int64),
                 ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
                 ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
-                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64)]
+                ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64), ('Gfb', C.c_int64)]
 
 
 class Tables(C.Structure):
@@ -71,6 +72,7 @@ PROTOTYPES = {
     'cffm_backward': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_backward_unscaled': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, _P]),
+    'cffm_train_step_opt': (C.c_int, [_SH, _TB, _TB, _TB, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     'cffm_train_step': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
 }
 
@@ -92,7 +94,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.cffm_abi_version() != 2:
+    if lib.cffm_abi_version() != 3:
         raise RuntimeError('cffm_amd: ABI version mismatch')
     _lib = lib
     return lib
@@ -113,7 +115,7 @@ def make_shape(cfg):
     return Shape(M=cfg.M, F=cfg.F, K=cfg.K, D=cfg.D, act=cfg.act_id, linear_att=cfg.linear_att,
                  inner_conv=cfg.inner_conv, outer_conv=cfg.outer_conv, loss=loss,
                  lamda_att=cfg.lamda_att, beta_outer=float(cfg.beta_outer), lr=cfg.lr,
-                 lamda=float(cfg.lamda_bilinear))
+                 lamda=float(cfg.lamda_bilinear), optimizer=OPT_IDS[cfg.optimizer])
 
 
 def theta_layout(shape):

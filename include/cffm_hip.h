@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 2
+#define CFFM_ABI_VERSION 3
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -42,6 +42,9 @@ enum { CFFM_ACT_RELU = 0, CFFM_ACT_PRELU = 1, CFFM_ACT_ELU = 2, CFFM_ACT_SELU = 
 /* loss ids, CFFM.py:486-514 (square_loss with lamda == 0 is the README default) */
 enum { CFFM_LOSS_SQUARE_RMSE = 0, CFFM_LOSS_MSE = 1, CFFM_LOSS_MAE = 2, CFFM_LOSS_LOG = 3,
        CFFM_LOSS_SQUARE_L2 = 4 /* square_loss with lamda > 0: l2_loss + table regularisers, CFFM.py:489-491 */ };
+
+/* optimizer ids, CFFM.py:517-529 */
+enum { CFFM_OPT_ADAGRAD = 0, CFFM_OPT_SGD = 1, CFFM_OPT_MOMENTUM = 2, CFFM_OPT_ADAM = 3 };
 
 typedef struct cffm_shape {
     int32_t M;            /* features_M                                   CFFM.py:110            */
@@ -57,6 +60,7 @@ typedef struct cffm_shape {
     float beta_outer;     /* CFFM.py:414                                                         */
     float lr;             /* CFFM.py:523                                                         */
     float lamda;          /* lamda_bilinear, only used by CFFM_LOSS_SQUARE_L2    CFFM.py:489-491          */
+    int32_t optimizer;    /* CFFM_OPT_*                                          CFFM.py:517-529          */
 } cffm_shape_t;
 
 /* Offsets (in floats) of the trained dense parameters inside ONE flat fp32 buffer "theta".  The same
@@ -95,7 +99,7 @@ typedef struct cffm_ws_layout {
     int64_t sort_keys, sort_vals;           /* int32 [B*F] each (sorted ids, source slots)         */
     int64_t sort_tmp;                       /* radix sort scratch                                  */
     int64_t sort_tmp_bytes;
-    int64_t Gi, Go;                         /* CFFM_LOSS_SQUARE_L2 only: dense table gradients [M,K], [M,D]   */
+    int64_t Gi, Go, Gfb;                    /* dense table gradients [M,K], [M,D], [M] (CFFM_LOSS_SQUARE_L2, CFFM_OPT_ADAM) */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
@@ -178,6 +182,13 @@ int cffm_dp_apply(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_ta
 int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,
                     float *theta, float *theta_acc, float *grad, const int32_t *ids, const float *y,
                     int32_t B, void *ws, float *loss, void *stream);
+
+/* The same step for the other optimizers of CFFM.py:517-529 (s->optimizer): state1 = Momentum accumulators / Adam m,
+ * state2 = Adam v (NULL otherwise), step = 1-based Adam time step.  Adagrad routes to cffm_train_step(state1). */
+int cffm_train_step_opt(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_state1,
+                        const cffm_tables_t *tab_state2, float *theta, float *theta_state1, float *theta_state2,
+                        float *grad, const int32_t *ids, const float *y, int32_t B, void *ws, float *loss, int64_t step,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -377,6 +377,80 @@ def init_accumulators(p):
     return {k: np.full_like(v, ADAGRAD_INIT_ACC) for k, v in p.items()}
 
 
+# --------------------------------------------------------------------------------------------
+# the other optimizers of create_optimizer (CFFM.py:519-529), TF-1.14 semantics
+#   GradientDescentOptimizer(lr)             v -= lr*g; sparse: duplicates accumulate (== summed)
+#   MomentumOptimizer(lr, 0.95)              a = 0.95*a + g; v -= lr*a; sparse: only the touched rows (duplicates summed first)
+#   AdamOptimizer(lr, 0.9, 0.999, 1e-8)      m,v moments; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); v -= lr_t*m/(sqrt(v)+eps);
+#                                            sparse (_apply_sparse_shared): m and v of EVERY row decay and every row moves
+# --------------------------------------------------------------------------------------------
+def init_opt_state(p, optimizer):
+    if optimizer == 'AdagradOptimizer':
+        return {'acc': init_accumulators(p)}
+    z = lambda: {k: np.zeros_like(v) for k, v in p.items()}
+    if optimizer == 'MomentumOptimizer':
+        return {'acc': z()}
+    if optimizer == 'AdamOptimizer':
+        return {'m': z(), 'v': z(), 't': 0}
+    return {}
+
+
+def _dense_table_grad(p, name, ids, rows):
+    g = np.zeros_like(p[name])
+    np.add.at(g, ids, rows.reshape(ids.shape[0], -1).reshape((ids.shape[0],) + p[name].shape[1:]))
+    return g
+
+
+def apply_optimizer(p, st, g, X, cfg):
+    opt, lr = cfg.optimizer, cfg.lr
+    ids = np.asarray(X).reshape(-1)
+    dense = {k: np.asarray(v).reshape(np.shape(p[k])) for k, v in g.items() if not k.startswith('d_') and not k.startswith('_')}
+    tabs = {'inner_embeddings': g.get('d_inner_rows'), 'outer_embeddings': g.get('d_outer_rows'), 'feature_bias': g['d_bias_rows']}
+    if opt == 'AdamOptimizer':
+        st['t'] += 1
+        b1, b2, eps, t = 0.9, 0.999, 1e-8, st['t']
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        for k, rows in tabs.items():
+            if rows is not None:
+                dense[k] = _dense_table_grad(p, k, ids, rows)          # every row takes part (zero gradient elsewhere)
+        for k, gk in dense.items():
+            st['m'][k] = b1 * st['m'][k] + (1 - b1) * gk
+            st['v'][k] = b2 * st['v'][k] + (1 - b2) * gk * gk
+            p[k] = p[k] - lr_t * st['m'][k] / (np.sqrt(st['v'][k]) + eps)
+        return
+    for k, gk in dense.items():
+        if opt == 'GradientDescentOptimizer':
+            p[k] = p[k] - lr * gk
+        else:                                                          # Momentum
+            st['acc'][k] = 0.95 * st['acc'][k] + gk
+            p[k] = p[k] - lr * st['acc'][k]
+    for k, rows in tabs.items():
+        if rows is None:
+            continue
+        uniq, inv = np.unique(ids, return_inverse=True)
+        summed = np.zeros((uniq.shape[0],) + p[k].shape[1:], dtype=p[k].dtype)
+        np.add.at(summed, inv, rows.reshape((ids.shape[0],) + p[k].shape[1:]))
+        if opt == 'GradientDescentOptimizer':
+            p[k][uniq] = p[k][uniq] - lr * summed
+        else:
+            a = 0.95 * st['acc'][k][uniq] + summed
+            st['acc'][k][uniq] = a
+            p[k][uniq] = p[k][uniq] - lr * a
+
+
+def train_step_opt(p, st, X, y, cfg, cache_hook=None):
+    """train_step for any optimizer of CFFM.py:517-529 (st from init_opt_state)."""
+    if cfg.optimizer == 'AdagradOptimizer':
+        return train_step(p, st['acc'], X, y, cfg, cache_hook)
+    out, cache = forward(p, X, cfg)
+    if cache_hook is not None:
+        cache_hook(cache)
+    L, dout = loss_and_grad(out, y.astype(out.dtype), cfg, p)
+    g = backward(p, cache, dout.astype(out.dtype), cfg)
+    apply_optimizer(p, st, g, X, cfg)
+    return L, out
+
+
 def train_step(p, acc, X, y, cfg, cache_hook=None):
     """One ``sess.run((loss, optimizer))`` (CFFM.py:200): forward, loss, backward, Adagrad.
     Mutates p and acc in place; returns (loss, out_before_update).  ``cache_hook(cache)`` lets a test

@@ -396,3 +396,78 @@ def test_regularised_square_loss_step():
     touched = np.zeros(cfg.M, dtype=bool)
     touched[ids] = True
     np.testing.assert_array_equal(got['feature_bias'][~touched], p32['feature_bias'][~touched])
+
+
+@pytest.mark.parametrize('opt', ['GradientDescentOptimizer', 'MomentumOptimizer', 'AdamOptimizer'])
+@pytest.mark.parametrize('name', ['bookx-relu', 'frappe-selu'])
+def test_other_optimizers(name, opt):
+    """cffm_train_step_opt: the other create_optimizer branches (CFFM.py:519-529) against the oracle.  Step 1 is held
+    to the gradient tolerance propagated through the update rule (linear for SGD/Momentum; Adam's first step is
+    lr*g/(|g| + 1e-8/sqrt(1-b2)), a smoothed sign); step 2 (other ids) checks the slot state carried over: Momentum
+    leaves unlooked-up rows alone, Adam moves every row that has a non-zero first moment."""
+    cfg, p32, X, y = make_case(name)
+    cfg.optimizer, cfg.lr = opt, (0.01 if opt == 'AdamOptimizer' else 1e-4)
+    eng = engine_for(cfg, p32)
+    p64 = to64(p32)
+    B = X.shape[0]
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    eng.forward(Xd, yd)
+    torch.cuda.synchronize()
+    hook = lambda cache: adopt_device_kinks(cfg, eng, B, cache)
+    grads = oracle_dense_grads(p64, X, y, cfg, hook)
+    st = orc.init_opt_state(p64, opt)
+    L, _ = orc.train_step_opt(p64, st, X, y.astype(np.float64), cfg, cache_hook=hook)
+    loss = eng.train_step(Xd, yd)
+    torch.cuda.synchronize()
+    close(loss.cpu().numpy(), [L], 'loss')
+    got = eng.export_params()
+    e1 = 1e-8 / np.sqrt(0.001)
+    for k, v in got.items():
+        extra = None
+        if k in grads:
+            gk = grads[k].reshape(v.shape)
+            dg = 1e-5 * max(np.abs(gk).max(), 1e-30)
+            if opt == 'AdamOptimizer':
+                u = lambda t: cfg.lr * t / (np.abs(t) + e1)
+                # + 1e-5 of the step itself: w0 - lr*sign-like step can cancel to ~1e-8 (conv biases start at 0.01 = lr)
+                extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk))) + 1e-5 * cfg.lr
+            else:
+                extra = cfg.lr * dg * np.ones_like(gk)
+        close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
+    slots = eng.export_accumulators()
+    ref_slot = st['m'] if opt == 'AdamOptimizer' else st.get('acc')
+    if ref_slot is not None:
+        for k in ('inner_embeddings', 'outer_embeddings', 'dense_1_kernel', 'outer_layer_conv_weight_0'):
+            close(slots[k], ref_slot[k].reshape(slots[k].shape), 'slot ' + k, tol=2e-5)
+    if opt == 'AdamOptimizer':
+        v2 = eng.export_second_moments()
+        for k in ('outer_embeddings', 'dense_1_kernel'):
+            close(v2[k], st['v'][k].reshape(v2[k].shape), 'v ' + k, tol=4e-5)
+
+    # ---- second step on other ids
+    rng = np.random.default_rng(21)
+    X2 = rng.integers(0, cfg.M // 2, size=X.shape).astype(np.int32)
+    before = got
+    p1 = {k: np.array(v) for k, v in p64.items()}
+    orc.train_step_opt(p64, st, X2, y.astype(np.float64), cfg)
+    eng.train_step(torch.from_numpy(X2).cuda(), yd)
+    torch.cuda.synchronize()
+    got = eng.export_params()
+    only1 = np.setdiff1d(X.reshape(-1), X2.reshape(-1))
+    never = np.setdiff1d(np.arange(cfg.M), np.concatenate([X.reshape(-1), X2.reshape(-1)]))
+    assert only1.size and never.size
+    for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+        np.testing.assert_array_equal(got[k][never], p32[k][never])
+        moved = got[k][only1] != before[k][only1]
+        if opt == 'AdamOptimizer':
+            assert moved.mean() > 0.9, k                      # m != 0 keeps pushing the row
+        else:
+            assert not moved.any(), k
+    # the step-2 MOVE (slot state carried over from step 1) against the oracle's move
+    for k, v in got.items():
+        d_dev = v.astype(np.float64) - before[k].astype(np.float64)
+        d_ref = p64[k].reshape(v.shape) - p1[k].reshape(v.shape)
+        err = np.abs(d_dev - d_ref)
+        ok = err <= 1e-3 * max(np.abs(d_ref).max(), 1e-30) + 4e-7 * np.abs(v)
+        # Adam's smoothed sign flips on gradients within rounding of 0: allow a vanishing fraction of such elements
+        assert ok.mean() > (0.999 if opt == 'AdamOptimizer' else 0.99999), (k, float(ok.mean()), float(err.max()))

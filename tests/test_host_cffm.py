@@ -76,9 +76,11 @@ def test_batchers_follow_the_reference_rules(tmp_path):
     assert m.eva_termination([9, 1, 2, 3, 4, 5]) and not m.eva_termination([1, 2, 3, 4, 5])
 
 
-def test_optimizers_other_than_adagrad_are_refused(tmp_path):
-    with pytest.raises(NotImplementedError):
-        make(tmp_path, optimizer_type='AdamOptimizer')
+def test_optimizer_strings(tmp_path):
+    for name in ('AdamOptimizer', 'GradientDescentOptimizer', 'MomentumOptimizer'):   # CFFM.py:517-529
+        assert make(tmp_path, optimizer_type=name).config.optimizer == name
+    with pytest.raises(ValueError):
+        make(tmp_path, optimizer_type='RMSPropOptimizer')
 
 
 @pytest.mark.gpu

@@ -213,3 +213,54 @@ def test_regularised_square_loss_step_matches_twin():
     untouched[X.reshape(-1)] = False
     assert (p['inner_embeddings'][untouched] != p0['inner_embeddings'][untouched]).any()      # dense update
     np.testing.assert_array_equal(p['feature_bias'][untouched], p0['feature_bias'][untouched])  # still sparse
+
+
+@pytest.mark.parametrize('opt', ['GradientDescentOptimizer', 'MomentumOptimizer', 'AdamOptimizer'])
+def test_other_optimizers_match_torch(opt):
+    """Two steps of the other create_optimizer branches (CFFM.py:519-529) against torch autograd + the TF-1.14 update
+    formulas written out here (torch.optim.SGD for SGD / momentum 0.95; TF's Adam puts epsilon OUTSIDE the bias
+    correction, so that one is spelled out).  Sparse semantics: Momentum touches only the looked-up rows, Adam moves
+    every row."""
+    cfg, p, X, y = _setup(CASES[1])
+    cfg.optimizer, cfg.lr = opt, 0.01
+    p0 = {k: v.copy() for k, v in p.items()}
+    st = orc.init_opt_state(p, opt)
+    rng = np.random.default_rng(9)
+    X2 = rng.integers(0, cfg.M, size=X.shape)
+    for Xs in (X, X2):
+        orc.train_step_opt(p, st, Xs, y, cfg)
+
+    tp = _torch_params(p0)
+    live = [v for k, v in tp.items() if k not in ('outer_W', 'outer_b', 'outer_layer_conv_weight_%d' % (cfg.Lc - 1),
+                                                  'outer_layer_conv_bias_%d' % (cfg.Lc - 1))]
+    tables = ('inner_embeddings', 'outer_embeddings', 'feature_bias')
+    state = {k: [torch.zeros_like(v), torch.zeros_like(v)] for k, v in tp.items()}
+    for t, Xs in enumerate((X, X2), start=1):
+        for v in tp.values():
+            v.grad = None
+        twin.loss(twin.forward(tp, torch.tensor(Xs), cfg), torch.tensor(y), cfg).backward()
+        touched = torch.zeros(cfg.M, dtype=torch.bool)
+        touched[torch.tensor(Xs).reshape(-1)] = True
+        with torch.no_grad():
+            for k, v in tp.items():
+                if v.grad is None:
+                    continue
+                g = v.grad
+                rows = touched.reshape(-1, *([1] * (v.dim() - 1))) if k in tables else torch.ones_like(v, dtype=torch.bool)
+                if opt == 'GradientDescentOptimizer':
+                    v -= cfg.lr * g
+                elif opt == 'MomentumOptimizer':
+                    a = torch.where(rows, 0.95 * state[k][0] + g, state[k][0])
+                    state[k][0] = a
+                    v -= torch.where(rows, cfg.lr * a, torch.zeros_like(a))
+                else:
+                    m = 0.9 * state[k][0] + 0.1 * g
+                    s2 = 0.999 * state[k][1] + 0.001 * g * g
+                    state[k] = [m, s2]
+                    v -= cfg.lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (torch.sqrt(s2) + 1e-8)
+    assert len(live) > 10
+    for k, v in tp.items():
+        np.testing.assert_allclose(p[k], v.detach().numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+    if opt == 'AdamOptimizer':        # rows seen in step 1 but not in step 2 still move in step 2
+        only1 = np.setdiff1d(X.reshape(-1), X2.reshape(-1))
+        assert only1.size and st['t'] == 2
