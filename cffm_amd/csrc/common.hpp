@@ -44,6 +44,8 @@ static inline int check_shape(const cffm_shape_t* s) {
     if (s->M < 1) return CFFM_ERR_BAD_SHAPE;
     if (ilog2_i(s->D) - 1 > CFFM_MAX_LAYERS) return CFFM_ERR_BAD_SHAPE;
     if (s->act < 0 || s->act > CFFM_ACT_GELU) return CFFM_ERR_BAD_SHAPE;
+    if (s->loss < 0 || s->loss > CFFM_LOSS_HYBRID) return CFFM_ERR_BAD_SHAPE;
+    if (s->optimizer < 0 || s->optimizer > CFFM_OPT_ADAM) return CFFM_ERR_BAD_SHAPE;
     return 0;
 }
 

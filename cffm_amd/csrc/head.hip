@@ -56,7 +56,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     for (int64_t e = tid; e < a.back_len; e += 256) s_d1w[e] = 0.f;          // d1_w is the first member of the range
     __syncthreads();
     float sum = 0.f;
-    if (a.unscaled) {
+    float hybrid_log = 0.f;
+    if (a.loss == CFFM_LOSS_HYBRID) {      // two sums with different normalisers: taken from out / y directly
+        float p_sq = 0.f, p_log = 0.f;
+        for (int i = tid; i < a.B; i += 256) {
+            const float o = a.out[i], yy = a.y[i];
+            p_sq += 0.5f * (yy - o) * (yy - o);
+            p_log -= yy * logf(o + 1e-7f) + (1.f - yy) * logf(1.f - o + 1e-7f);
+        }
+        sum = block_sum(p_sq, red);
+        __syncthreads();
+        hybrid_log = block_sum(p_log, red);
+        __syncthreads();
+    } else if (a.unscaled) {
         sum = 0.f;           // not known yet: the caller all-reduces it together with the gradients
     } else if (a.sqerr) {    // same fixed-order sum in every workgroup
         float part = 0.f;
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     float L;
     if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = a.unscaled ? 1.f : sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
     else if (a.loss == CFFM_LOSS_SQUARE_L2) L = sum;            // data term only (the regularisers are not summed here)
+    else if (a.loss == CFFM_LOSS_HYBRID) L = 0.5f * sum + 0.5f * hybrid_log * invB;   // CFFM.py:511-513
     else L = sum * invB;
     if (blockIdx.x == 0 && tid == 0) {
         a.scalars[1] = L;
@@ -87,6 +100,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
             case CFFM_LOSS_MSE: d = 2.f * (out - y) * invB; break;
             case CFFM_LOSS_MAE: d = (out > y ? 1.f : (out < y ? -1.f : 0.f)) * invB; break;
             case CFFM_LOSS_SQUARE_L2: d = out - y; break;        // d/dout of sum (y - out)^2 / 2
+            case CFFM_LOSS_HYBRID:
+                d = 0.5f * (out - y) - 0.5f * invB * (y / (out + 1e-7f) - (1.f - y) / (1.f - out + 1e-7f));
+                break;
             default: {
                 const float s = out;   // ws.out holds sigmoid(logit) for log_loss
                 d = -(y / (s + 1e-7f) - (1.f - y) / (1.f - s + 1e-7f)) * invB * s * (1.f - s);

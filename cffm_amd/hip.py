@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
-LOSS_IDS = {'square_loss': 0, 'mse': 1, 'mae': 2, 'log_loss': 3}
+LOSS_IDS = {'square_loss': 0, 'mse': 1, 'mae': 2, 'log_loss': 3, 'hybrid': 5}
 OPT_IDS = {'AdagradOptimizer': 0, 'GradientDescentOptimizer': 1, 'MomentumOptimizer': 2, 'AdamOptimizer': 3}
 
 

@@ -41,7 +41,8 @@ extern "C" {
 enum { CFFM_ACT_RELU = 0, CFFM_ACT_PRELU = 1, CFFM_ACT_ELU = 2, CFFM_ACT_SELU = 3, CFFM_ACT_GELU = 4 };
 /* loss ids, CFFM.py:486-514 (square_loss with lamda == 0 is the README default) */
 enum { CFFM_LOSS_SQUARE_RMSE = 0, CFFM_LOSS_MSE = 1, CFFM_LOSS_MAE = 2, CFFM_LOSS_LOG = 3,
-       CFFM_LOSS_SQUARE_L2 = 4 /* square_loss with lamda > 0: l2_loss + table regularisers, CFFM.py:489-491 */ };
+       CFFM_LOSS_SQUARE_L2 = 4 /* square_loss with lamda > 0: l2_loss + table regularisers, CFFM.py:489-491 */,
+       CFFM_LOSS_HYBRID = 5 /* 0.5*l2_loss(y-out) + 0.5*log_loss(out, y) on the RAW out (NaN once out+1e-7 <= 0), CFFM.py:510-513 */ };
 
 /* optimizer ids, CFFM.py:517-529 */
 enum { CFFM_OPT_ADAGRAD = 0, CFFM_OPT_SGD = 1, CFFM_OPT_MOMENTUM = 2, CFFM_OPT_ADAM = 3 };

@@ -242,6 +242,12 @@ def loss_and_grad(out, y, cfg, p=None):
         L = -np.mean(y * np.log(s + eps) + (1 - y) * np.log(1 - s + eps))
         dLds = -(y / (s + eps) - (1 - y) / (1 - s + eps)) / B
         return L, dLds * s * (1 - s)
+    if lt == 'hybrid':                                                 # :510-513, log_loss on the RAW out
+        eps = 1e-7
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ll = -np.mean(y * np.log(out + eps) + (1 - y) * np.log(1 - out + eps))
+        L = 0.5 * 0.5 * np.sum((y - out) ** 2) + 0.5 * ll
+        return L, 0.5 * (out - y) - 0.5 * (y / (out + eps) - (1 - y) / (1 - out + eps)) / B
     raise ValueError('unsupported loss_type %r' % (lt,))
 
 

@@ -70,13 +70,14 @@ def test_workspace_layout(lib):
 
 def test_bad_shapes_are_rejected(lib):
     tl = hip.ThetaLayout()
-    for kw in (dict(F=1), dict(D=24), dict(D=2), dict(K=6), dict(F=65)):
+    for kw in (dict(F=1), dict(D=24), dict(D=2), dict(K=6), dict(F=65), dict(loss=6), dict(optimizer=4), dict(act=9)):
         base = dict(M=10, F=3, K=8, D=8, act=0, linear_att=1, inner_conv=1, outer_conv=1, loss=0,
                     lamda_att=1.0, beta_outer=1.0, lr=0.05)
         base.update(kw)
         assert lib.cffm_theta_layout(C.byref(hip.Shape(**base)), C.byref(tl)) == 10001
     with pytest.raises(ValueError):
-        hip.make_shape(CFFMConfig(M=10, F=3, loss_type='hybrid'))
+        hip.make_shape(CFFMConfig(M=10, F=3, loss_type='hinge'))
+    assert hip.make_shape(CFFMConfig(M=10, F=3, loss_type='hybrid')).loss == 5
 
 
 def test_engine_refuses_to_run_without_gpu():

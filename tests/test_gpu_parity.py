@@ -242,15 +242,19 @@ def test_second_step_and_reproducibility():
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=1e-4)
 
 
-@pytest.mark.parametrize('loss', ['mse', 'mae', 'log_loss'])
+@pytest.mark.parametrize('loss', ['mse', 'mae', 'log_loss', 'hybrid'])
 def test_other_losses(loss):
     CASES['tmp-' + loss] = dict(M=80, F=4, K=8, D=8, act='elu', B=12, loss=loss)
-    cfg, p32, X, y = make_case('tmp-' + loss)
+    cfg, p32, X, y = make_case('tmp-' + loss, trained_like=(loss != 'hybrid'))
     if loss == 'log_loss':
         y = (y > 0).astype(np.float32)
+    if loss == 'hybrid':               # log_loss on the raw out (CFFM.py:511-513) is finite only for 0 < out < 1
+        p32['bias'] = np.float32(0.5)
     eng = engine_for(cfg, p32)
     p64 = to64(p32)
     out_ref, c = orc.forward(p64, X, cfg)
+    if loss == 'hybrid':
+        assert (out_ref > 0.05).all() and (out_ref < 0.95).all()
     L, dout = orc.loss_and_grad(out_ref, y.astype(np.float64), cfg, p64)
     B = X.shape[0]
     yt = torch.from_numpy(y).cuda()

@@ -73,12 +73,14 @@ def test_forward_and_grads_match_torch_twin(case, linear_att):
     assert dead not in g and tp[dead].grad is None
 
 
-@pytest.mark.parametrize('loss_type', ['mse', 'mae', 'log_loss'])
+@pytest.mark.parametrize('loss_type', ['mse', 'mae', 'log_loss', 'hybrid'])
 def test_other_losses_match_twin(loss_type):
     cfg, p, X, y = _setup(CASES[1], loss_type=loss_type)
     if loss_type == 'log_loss':
         y = (y > 0).astype(np.float64)
     out, _ = orc.forward(p, X, cfg)
+    if loss_type == 'hybrid':          # finite only while 0 < out < 1 (the reference feeds the raw out to log_loss)
+        out = 0.5 + 0.4 * np.tanh(out)
     L, dout = orc.loss_and_grad(out, y, cfg, p)
     to = torch.tensor(out, requires_grad=True)
     tL = twin.loss(to, torch.tensor(y), cfg)

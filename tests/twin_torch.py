@@ -85,4 +85,7 @@ def loss(out, y, cfg, p=None):
     if cfg.loss_type == 'log_loss':
         s = torch.sigmoid(out)
         return -torch.mean(y * torch.log(s + 1e-7) + (1 - y) * torch.log(1 - s + 1e-7))
+    if cfg.loss_type == 'hybrid':
+        ll = -torch.mean(y * torch.log(out + 1e-7) + (1 - y) * torch.log(1 - out + 1e-7))
+        return 0.5 * (0.5 * torch.sum((y - out) ** 2)) + 0.5 * ll
     raise ValueError(cfg.loss_type)
