@@ -34,11 +34,57 @@ from cffm_amd.engine import HipEngine  # noqa: E402
 from cffm_amd.spec import CFFMConfig, init_params  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 N_POOL = 64                    # distinct synthetic batches cycled through
+
+# BASELINE.json configs (README.md:20-28 commands; configs[3] is the synthetic stress shape).  The default, and the
+# only one the contract line is quoted on, is frappe; the others are there for profiling.
+WORKLOADS = {
+    'frappe': dict(M=5382, F=10, K=32, D=32, act='selu', B=256,
+                   text='frappe shape: synthetic libfm, 10 fields, 5382 features, inner/outer dim 32, batch 256 per '
+                        'GPU, selu, Adagrad lr 0.05, square_loss (README.md:28)'),
+    'mltag': dict(M=90445, F=3, K=32, D=32, act='elu', B=1024,
+                  text='ml-tag shape: 3 fields, 90445 features, dim 32, batch 1024 per GPU, elu (README.md:24)'),
+    'bookx': dict(M=226336, F=6, K=32, D=32, act='relu', B=512,
+                  text='book-crossing shape: 6 fields, 226336 features, dim 32, batch 512 per GPU, relu (README.md:20)'),
+    'syn1m': dict(M=1000000, F=32, K=64, D=64, act='relu', B=8192,
+                  text='synthetic stress shape: 32 fields, 1M features, dim 64, batch 8192 per GPU, relu'),
+}
+
+
+def workload_cfg(name):
+    w = WORKLOADS[name]
+    return CFFMConfig(M=w['M'], F=w['F'], K=w['K'], D=w['D'], activation=w['act'], lr=0.05, lamda_att=1.0), w['B']
 
 
 def frappe_cfg():
-    return CFFMConfig(M=5382, F=10, K=32, D=32, activation='selu', lr=0.05, lamda_att=1.0)
+    return workload_cfg('frappe')[0]
+
+
+def step_flops_per_example(cfg):
+    """Reference-algorithm FLOPs of one train step per example, live layers only: 3 x forward."""
+    P, D, K, Lc = cfg.P, cfg.D, cfg.K, cfg.Lc
+    fwd = P * D * D + sum(2 * (D >> (l + 1)) ** 2 * 4 * P * P for l in range(Lc - 1)) + P * D * D + 7 * P * K \
+        + 2 * (2 * D - 2) * 32
+    return 3 * fwd
+
+
+def measured_peaks(device):
+    """What THIS box delivers on the two rooflines: a float4 streaming copy of 1 GiB (read + write counted) and a
+    dependency-free fp32 MFMA loop on every CU (cffm_probe_copy / cffm_probe_mfma)."""
+    lib = hip.load()
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = event_time_ms(lambda: hip.check(lib.cffm_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, st)), 20)
+    copy_gbs = 2 * n / (ms * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    out = torch.zeros(4, device=device)
+    flops = C.c_int64(0)
+    ms = event_time_ms(lambda: hip.check(lib.cffm_probe_mfma(C.c_void_p(out.data_ptr()), 20000, C.byref(flops), st)), 5)
+    return {'hbm_copy_GBs': round(copy_gbs, 1), 'mfma_f32_TFLOPs': round(flops.value / (ms * 1e-3) / 1e12, 1)}
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -124,8 +170,13 @@ def stage_times(eng, ids, y):
     return out
 
 
-def cpu_baseline(cfg, X, y, budget_s=12.0):
+def cpu_baseline(cfg, X, y, budget_s=9.0):
+    """Two CPU restatements of the TF1 graph (the reference itself needs TensorFlow 1.14 and cannot run here) on the
+    same batches, fp32, on this box's host cores: the numpy oracle and the torch-CPU autograd twin (conv2d /
+    max_pool2d / matmul with torch's intra-op thread pool, the closest stand-in for TF's Eigen pool).  The faster one
+    is the reported value."""
     from oracle import cffm_oracle as orc
+    from oracle import cffm_twin_torch as twin
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
@@ -139,9 +190,29 @@ def cpu_baseline(cfg, X, y, budget_s=12.0):
         orc.train_step(p, acc, X[(n + 1) % X.shape[0]], y[(n + 1) % X.shape[0]], cfg)
         n += 1
     dt = time.perf_counter() - t0
-    return {'value': round(n * X.shape[1] / dt, 1), 'unit': 'examples/s', 'cores': int(threads), 'kind': 'port',
-            'sample': '%d fp32 train steps of the numpy oracle (op-by-op restatement of the TF1 graph, materialises '
-                      'the outer map) on the same batches, %.1f s; host has %d cores' % (n, dt, os.cpu_count() or 0)}
+    numpy_rate = n * X.shape[1] / dt
+
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    tthreads = max(1, min(ncpu, 64))
+    torch.set_num_threads(tthreads)
+    tp = {k: torch.tensor(np.asarray(v, dtype=np.float32), requires_grad=True)
+          for k, v in init_params(cfg, seed=2021, dtype=np.float32).items()}
+    tacc = {k: torch.full_like(v, 1e-8) for k, v in tp.items()}
+    Xt, yt = torch.from_numpy(X).long(), torch.from_numpy(y)
+    twin.train_step(tp, tacc, Xt[0], yt[0], cfg)
+    m, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and m < 400:
+        twin.train_step(tp, tacc, Xt[(m + 1) % X.shape[0]], yt[(m + 1) % X.shape[0]], cfg)
+        m += 1
+    dt2 = time.perf_counter() - t0
+    torch_rate = m * X.shape[1] / dt2
+    best_torch = torch_rate >= numpy_rate
+    return {'value': round(max(torch_rate, numpy_rate), 1), 'unit': 'examples/s',
+            'cores': int(tthreads if best_torch else threads), 'kind': 'port',
+            'sample': 'fp32 train steps on the same batches: torch-CPU twin %d steps in %.1f s = %.0f ex/s (%d threads); '
+                      'numpy oracle %d steps in %.1f s = %.0f ex/s (%d BLAS threads); host has %d cores; value = the '
+                      'faster' % (m, dt2, torch_rate, tthreads, n, dt, numpy_rate, threads, os.cpu_count() or 0),
+            'torch_cpu': round(torch_rate, 1), 'numpy_oracle': round(numpy_rate, 1)}
 
 
 def main():
@@ -151,37 +222,55 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
+    ap.add_argument('--workload', default='frappe', choices=sorted(WORKLOADS),
+                    help='frappe is the contract workload; the others are for profiling')
+    ap.add_argument('--tables', default='replicated', choices=['replicated', 'sharded'],
+                    help='sharded: row-sharded tables (cffm_amd.dist.ShardedStep), the mode for vocabularies beyond one GPU')
+    ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    use_pg = world > 1 or args.tables == 'sharded'
+    if use_pg:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)'
                          % (args.gpus, world))
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    cfg = frappe_cfg()
-    B = 256                                             # per GPU: weak scaling, global batch = 256 * N
-    eng = HipEngine(cfg, seed=2021, device=str(device))
-    Xh, yh = synth.batches(cfg.M, cfg.F, B, N_POOL * world, seed=2021, dist=args.dist)
+    cfg, B = workload_cfg(args.workload)                # B per GPU: weak scaling, global batch = B * N
+    n_pool = N_POOL if args.workload != 'syn1m' else 4
+    Xh, yh = synth.batches(cfg.M, cfg.F, B, n_pool * world, seed=2021, dist=args.dist)
     Xh, yh = Xh[rank::world], yh[rank::world]            # every rank its own shard of every global batch
     X = torch.from_numpy(Xh).to(device)
     y = torch.from_numpy(yh).to(device)
 
-    if world > 1:
-        import torch.distributed as dist
+    if args.tables == 'sharded':
+        import copy
+        from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
+        lcfg = copy.copy(cfg)
+        lcfg.M = local_rows_count(cfg.M, rank, world)
+        eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=2021), rank, world), device=str(device))
+        sh = ShardedStep(eng)
+        step = lambda i: sh.train_step(X[i % n_pool], y[i % n_pool])
+        barrier = lambda: dist.barrier()
+    elif world > 1:
         from cffm_amd.dist import DataParallelStep
+        eng = HipEngine(cfg, seed=2021, device=str(device))
         dp = DataParallelStep(eng)
-        step = lambda i: dp.train_step(X[i % N_POOL], y[i % N_POOL])
+        step = lambda i: dp.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: dist.barrier()
     else:
-        step = lambda i: eng.train_step(X[i % N_POOL], y[i % N_POOL])
+        eng = HipEngine(cfg, seed=2021, device=str(device))
+        step = lambda i: eng.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: None
 
     for i in range(args.warmup):
@@ -194,13 +283,15 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(eng.loss_buf[0].item())
     if not np.isfinite(loss):
         raise SystemExit('bench.py: loss is not finite')
+    if args.workload == 'syn1m':
+        torch.cuda.empty_cache()
 
     if rank == 0:
         res = {
@@ -209,19 +300,36 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'frappe shape: synthetic libfm, 10 fields, 5382 features, inner/outer dim 32, '
-                                   'batch 256 per GPU, selu, Adagrad lr 0.05, square_loss (README.md:28)',
-                       'global_batch': B * world, 'id_distribution': args.dist,
+            'config': {'workload': WORKLOADS[args.workload]['text'],
+                       'global_batch': B * world, 'id_distribution': args.dist, 'tables': args.tables,
                        'parallelism': 'dp%d' % world if world > 1 else 'single'},
             'final_loss': round(loss, 6),
         }
-        if world == 1:
+        tf = step_flops_per_example(cfg) * B * world * args.steps / dt / 1e12
+        res['step_flops'] = {'reference_algorithm_TFLOPs': round(tf, 2), 'mfma_f32_peak_TFLOPs': MFMA_F32_PEAK_TFLOPS * world,
+                             'frac': round(tf / (MFMA_F32_PEAK_TFLOPS * world), 4),
+                             'note': 'conv0 runs factorised (rank-1 input channels), so executed FLOPs are lower'}
+        if world == 1 and not args.quick and args.tables == 'replicated':
+            # the same loop with the host-side batcher of CFFM.train in it (random start on the host, slice of the
+            # device-resident split): SURVEY 8d's "second figure including host batching"
+            Xall, yall = X.reshape(-1, cfg.F), y.reshape(-1)
+            nrow = Xall.shape[0]
+            rs = np.random.RandomState(2021)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                s0 = rs.randint(0, nrow - B)
+                eng.train_step(Xall[s0:s0 + B], yall[s0:s0 + B])
+            torch.cuda.synchronize()
+            res['value_with_host_batching'] = round(B * args.steps / (time.perf_counter() - t0), 1)
             res['stage_us'] = stage_times(eng, X[0], y[0])
+            del X, y
             res['roofline'] = gather_roofline(device)
-            if not args.no_cpu_baseline:
+            res['roofline']['measured_peaks'] = measured_peaks(device)
+            if not args.no_cpu_baseline and args.workload != 'syn1m':
                 res['cpu_baseline'] = cpu_baseline(cfg, Xh, yh)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -105,7 +105,11 @@ static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const f
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
     const Geo g = make_geo(s);
-    if (fused_step && s->inner_conv && s->outer_conv) {
+    if (!tab) {
+        // row-sharded tables: the rows came in over the wire and are already staged in ws.Ei / ws.Eo / ws.fb
+        if (fused_step) return CFFM_ERR_UNSUPPORTED;
+        if ((rc = cffm_inner_fwd(s, theta, ws, B, stream))) return rc;
+    } else if (fused_step && s->inner_conv && s->outer_conv) {
         // the inner-branch kernel gathers the rows of its example itself (one launch less)
         if ((rc = cffm_inner_fwd_impl(s, theta, ws, B, tab, ids, stream))) return rc;
     } else {

@@ -122,3 +122,65 @@ class ShardedTables(object):
             dist.all_to_all_single(recv, send, rc, sc, group=self.group)
             out[name] = recv
         return local_rows, out
+
+
+def local_rows_count(M, rank, world):
+    """Rows of an M-row table owned by ``rank`` under r -> (r % G, r // G)."""
+    return (M - rank + world - 1) // world
+
+
+def shard_params(params, rank, world):
+    """Global parameter dict -> this rank's view: the three tables keep rows rank, rank+G, ...; the rest is replicated."""
+    out = dict(params)
+    for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+        out[k] = params[k][rank::world].copy()
+    return out
+
+
+class ShardedStep(object):
+    """Training step with ROW-SHARDED tables (vocabulary beyond one GPU's HBM; cfg5 of BASELINE.json): dense parameters
+    replicated, row r of the three tables and of their Adagrad accumulators on rank r % G at local row r // G.
+
+        route ids by owner -> all-to-all (ids) -> owner-side gather -> all-to-all (rows back, one packed message)
+        -> forward_rows / backward_unscaled (local) -> all-reduce [dense grad | loss sum]
+        -> all-to-all (packed row gradients, keyed by the owner's local row) -> dp_apply on the owner:
+           1/L, dense Adagrad (identical on every rank), duplicates-summed-first sparse Adagrad over the rows it owns
+
+    Exchange volume scales with the B*F lookups of the batch, never with the vocabulary.  ``compute`` owns a LOCAL
+    engine (cfg.M = local_rows_count): HipEngine in the product, the oracle in the CPU tests."""
+
+    def __init__(self, compute, group=None):
+        self.c = compute
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _a2a(self, send, send_counts, recv_counts):
+        recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group)
+        return recv
+
+    def train_step(self, ids, y):
+        c, G = self.c, self.world
+        B, F = ids.shape
+        Bg = B * G
+        flat = ids.reshape(-1).long()
+        perm, send_counts = route_ids(flat, G)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()              # the one host sync of the step
+        # 1) ask the owners for rows, by their local row index
+        want = (flat[perm] // G).to(torch.int32).contiguous()
+        asked = self._a2a(want, sc, rc)
+        rows = c.gather_packed(asked)                                    # [m, K+D+1] on the owner
+        got = self._a2a(rows, rc, sc)                                    # back in routed order
+        staged = torch.empty_like(got)
+        staged[perm] = got                                               # caller's (example, field) order
+        K, D = c.cfg.K, c.cfg.D
+        c.forward_rows(staged[:, :K].contiguous(), staged[:, K:K + D].contiguous(), staged[:, K + D].contiguous(), y, B)
+        # 2) local backward, gradients keyed by the owner's local row
+        local_ids = (flat // G).to(torch.int32).reshape(B, F).contiguous()
+        grad, packed = c.backward_unscaled(local_ids, y, B, Bg)
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+        recv = self._a2a(packed[perm].contiguous(), sc, rc)
+        return c.dp_apply(grad, recv, Bg)

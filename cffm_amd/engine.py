@@ -239,6 +239,34 @@ class HipEngine(object):
         hip.check(self.lib.cffm_forward(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
                                         _ptr(y), B, _ptr(buf), self._stream()))
 
+    def gather_packed(self, local_rows):
+        """Owner side of a row-sharded lookup: int32 [m] local rows -> [m, K+D+1] = (inner | outer | bias) rows."""
+        m = int(local_rows.numel())
+        K, D = self.cfg.K, self.cfg.D
+        out = torch.empty((m, K + D + 1), dtype=torch.float32, device=self.device)
+        if m:
+            F = self.cfg.F
+            Bp = -(-m // F)                                  # cffm_gather takes whole [B,F] id blocks: pad with row 0
+            ids = torch.zeros(Bp * F, dtype=torch.int32, device=self.device)
+            ids[:m] = local_rows.reshape(-1)
+            Ei, Eo, fb = self.gather(ids.reshape(Bp, F))
+            out[:, :K] = Ei.reshape(Bp * F, K)[:m]
+            out[:, K:K + D] = Eo.reshape(Bp * F, D)[:m]
+            out[:, K + D] = fb.reshape(Bp * F)[:m]
+        return out
+
+    def forward_rows(self, Ei, Eo, fb, y, B=None):
+        """Forward from rows that are already looked up (row-sharded tables, cffm_amd/dist.py): Ei [B,F,K], Eo [B,F,D],
+        fb [B,F] are staged into the workspace and cffm_forward runs without its gather."""
+        F = self.cfg.F
+        B = Ei.numel() // (F * self.cfg.K) if B is None else B
+        buf, _ = self.workspace(B)
+        self.ws_tensor(B, 'Ei', (B, F, self.cfg.K)).copy_(Ei.reshape(B, F, self.cfg.K))
+        self.ws_tensor(B, 'Eo', (B, F, self.cfg.D)).copy_(Eo.reshape(B, F, self.cfg.D))
+        self.ws_tensor(B, 'fb', (B, F)).copy_(fb.reshape(B, F))
+        hip.check(self.lib.cffm_forward(C.byref(self.shape), None, _ptr(self.theta), None, _ptr(y), B, _ptr(buf),
+                                        self._stream()))
+
     def backward(self, y, B, B_global=None):
         buf, _ = self.workspace(B)
         hip.check(self.lib.cffm_backward(C.byref(self.shape), _ptr(self.theta), _ptr(y), int(B),

@@ -162,7 +162,8 @@ int cffm_sparse_adagrad(const cffm_shape_t *s, const cffm_tables_t *tab, const c
 /* sess.run(self.out) CFFM.py:596: ids [B,F] -> out [B] (also left in ws.out) */
 int cffm_predict(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids,
                  int32_t B, void *ws, float *out, void *stream);
-/* forward half of a train step, through the per-example loss terms */
+/* forward half of a train step, through the per-example loss terms.  tab == NULL: the looked-up rows are already
+ * staged in ws.Ei / ws.Eo / ws.fb (row-sharded tables: they arrived from their owner ranks) and ids is not read */
 int cffm_forward(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids,
                  const float *y, int32_t B, void *ws, void *stream);
 /* backward half: needs scalars[3] = global loss-term sum (cffm_train_step copies scalars[0] there) */
@@ -183,6 +184,12 @@ int cffm_dp_apply(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_ta
 int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,
                     float *theta, float *theta_acc, float *grad, const int32_t *ids, const float *y,
                     int32_t B, void *ws, float *loss, void *stream);
+
+/* ---- peak probes (bench.py prices the kernels against the data-sheet peaks AND these measured ones) ------------- */
+/* float4 streaming copy src -> dst (bytes % 16 == 0): 2*bytes of HBM traffic per launch */
+int cffm_probe_copy(const void *src, void *dst, int64_t bytes, void *stream);
+/* dependency-free fp32 MFMA loop over the whole chip; *flops receives the flop count of the launch */
+int cffm_probe_mfma(float *out, int32_t iters, int64_t *flops, void *stream);
 
 /* The same step for the other optimizers of CFFM.py:517-529 (s->optimizer): state1 = Momentum accumulators / Adam m,
  * state2 = Adam v (NULL otherwise), step = 1-based Adam time step.  Adagrad routes to cffm_train_step(state1). */

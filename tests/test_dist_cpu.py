@@ -104,6 +104,35 @@ class OracleCompute(object):
         return torch.tensor([L])
 
 
+class ShardedOracleCompute(OracleCompute):
+    """The same stand-in over a LOCAL table shard (rows rank, rank+G, ...) for ShardedStep."""
+
+    def gather_packed(self, local_rows):
+        r = local_rows.numpy().astype(np.int64)
+        return torch.from_numpy(np.concatenate([self.p['inner_embeddings'][r], self.p['outer_embeddings'][r],
+                                                self.p['feature_bias'][r].reshape(-1, 1)], axis=1))
+
+    def forward_rows(self, Ei, Eo, fb, y, B):
+        F = self.cfg.F
+        q = dict(self.p)                       # the looked-up rows act as a private B*F-row table
+        q['inner_embeddings'], q['outer_embeddings'] = Ei.numpy(), Eo.numpy()
+        q['feature_bias'] = fb.numpy().reshape(-1, 1)
+        self.X = np.arange(B * F).reshape(B, F)
+        self.out, self.cache = orc.forward(q, self.X, self.cfg)
+        self._q = q
+        self.sc[0] = float(np.sum((y.numpy() - self.out) ** 2))
+
+    def backward_unscaled(self, ids, y, B, Bg):
+        p, self.p = self.p, self._q
+        try:
+            self.X_save = self.X
+            grad, rows = OracleCompute.backward_unscaled(self, ids, y, B, Bg)
+        finally:
+            self.p = p
+        rows[:, 0] = ids.reshape(-1).to(torch.float64)          # keyed by the owner's local row
+        return grad, rows
+
+
 def _case():
     cfg = CFFMConfig(M=50, F=4, K=8, D=8, activation='selu', lamda_att=1.5)
     p = init_params(cfg, seed=3, dtype=np.float64)
@@ -138,6 +167,38 @@ def test_data_parallel_step_equals_single_process_step():
             np.testing.assert_allclose(v, p[k], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
     for k in res[0][1]:                           # replicas stay bit-identical
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+
+
+def _sharded_step_worker(rank, world):
+    from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
+    cfg, p, X, y = _case()
+    import copy
+    lcfg = copy.copy(cfg)
+    lcfg.M = local_rows_count(cfg.M, rank, world)
+    comp = ShardedOracleCompute(lcfg, shard_params(p, rank, world))
+    assert comp.p['inner_embeddings'].shape[0] == lcfg.M
+    step = ShardedStep(comp)
+    sl = slice(rank * 4, rank * 4 + 4)
+    loss = step.train_step(torch.from_numpy(X[sl]), torch.from_numpy(y[sl]))
+    return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}, {k: np.asarray(v) for k, v in comp.acc.items()}
+
+
+def test_row_sharded_step_equals_single_process_step():
+    """cfg5's mode: tables row-sharded r -> rank r % 2, batch split in halves; afterwards the union of the shards and
+    every replicated parameter equal ONE oracle step on the whole batch with whole tables."""
+    res = _run(_sharded_step_worker, 2)
+    cfg, p, X, y = _case()
+    acc = orc.init_accumulators(p)
+    L, _ = orc.train_step(p, acc, X, y, cfg)
+    for rank in (0, 1):
+        loss, got, gacc = res[rank]
+        assert abs(loss - L) < 1e-12
+        for k, v in got.items():
+            if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+                np.testing.assert_allclose(v, p[k][rank::2], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
+                np.testing.assert_allclose(gacc[k], acc[k][rank::2], rtol=1e-10, atol=1e-14)
+            else:
+                np.testing.assert_allclose(v, p[k], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
 
 
 def _shard_worker(rank, world):

@@ -475,3 +475,57 @@ def test_other_optimizers(name, opt):
         ok = err <= 1e-3 * max(np.abs(d_ref).max(), 1e-30) + 4e-7 * np.abs(v)
         # Adam's smoothed sign flips on gradients within rounding of 0: allow a vanishing fraction of such elements
         assert ok.mean() > (0.999 if opt == 'AdamOptimizer' else 0.99999), (k, float(ok.mean()), float(err.max()))
+
+
+def test_row_sharded_halves_on_one_gpu():
+    """cfg5's mode (row-sharded tables) without a second GPU: two engines each own the rows r % 2 == rank of the three
+    tables; the test plays the all-to-alls of cffm_amd.dist.ShardedStep (ids to the owner, rows back, packed row
+    gradients to the owner) and the all-reduce.  Union of the shards + replicated parameters == one oracle step on
+    the whole batch with whole tables."""
+    import copy
+    from cffm_amd.dist import local_rows_count, shard_params
+    from cffm_amd.engine import HipEngine
+    cfg, p32, X, y = make_case('bookx-relu')
+    B, F, G = X.shape[0], cfg.F, 2
+    h = B // 2
+    K, D = cfg.K, cfg.D
+    engines = []
+    for r in range(G):
+        lc = copy.copy(cfg)
+        lc.M = local_rows_count(cfg.M, r, G)
+        engines.append(HipEngine(lc, params=shard_params(p32, r, G)))
+    halves = [X[:h], X[h:]]
+    ys = [torch.from_numpy(y[:h]).cuda(), torch.from_numpy(y[h:]).cuda()]
+    grads, packed = [], []
+    for r in range(G):
+        flat = torch.from_numpy(halves[r].reshape(-1)).cuda().long()
+        staged = torch.empty((flat.numel(), K + D + 1), device='cuda')
+        for o in range(G):                               # "all-to-all": ask owner o for its rows
+            m = (flat % G) == o
+            staged[m] = engines[o].gather_packed((flat[m] // G).to(torch.int32))
+        e = engines[r]
+        e.forward_rows(staged[:, :K].contiguous(), staged[:, K:K + D].contiguous(), staged[:, K + D].contiguous(), ys[r], h)
+        g, rows = e.backward_unscaled((flat // G).to(torch.int32).reshape(h, F), ys[r], h, B)
+        grads.append(g.clone()); packed.append((flat % G, rows.clone()))
+    torch.cuda.synchronize()
+    gsum = grads[0] + grads[1]
+    p64 = to64(p32)
+    grads_ref = oracle_dense_grads(p64, X, y, cfg)
+    acc = orc.init_accumulators(p64)
+    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
+    for o in range(G):
+        recv = torch.cat([rows[own == o] for own, rows in packed], dim=0).contiguous()
+        loss = engines[o].dp_apply(gsum.clone(), recv, B)
+        torch.cuda.synchronize()
+        close(loss.cpu().numpy(), [L], 'loss')
+        got = engines[o].export_params()
+        for k, v in got.items():
+            ref = p64[k][o::G] if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias') else p64[k]
+            extra = None
+            if k in grads_ref:
+                gk = grads_ref[k][o::G] if ref is not p64[k] else grads_ref[k]
+                gk = gk.reshape(v.shape)
+                dg = 2e-5 * max(np.abs(grads_ref[k]).max(), 1e-30)
+                u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
+                extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
+            close(v, ref.reshape(v.shape), 'rank %d param %s' % (o, k), tol=2e-5, extra=extra)

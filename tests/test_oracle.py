@@ -266,3 +266,17 @@ def test_other_optimizers_match_torch(opt):
     if opt == 'AdamOptimizer':        # rows seen in step 1 but not in step 2 still move in step 2
         only1 = np.setdiff1d(X.reshape(-1), X2.reshape(-1))
         assert only1.size and st['t'] == 2
+
+
+def test_twin_train_step_equals_oracle_train_step():
+    """The threaded torch CPU step bench.py times as cpu_baseline is the same step as the numpy oracle's."""
+    cfg, p, X, y = _setup(CASES[2])
+    tp = _torch_params(p)
+    tacc = {k: torch.full_like(v, 1e-8) for k, v in tp.items()}
+    acc = orc.init_accumulators(p)
+    for _ in range(2):
+        L = orc.train_step(p, acc, X, y, cfg)[0]
+        tL = twin.train_step(tp, tacc, torch.tensor(X), torch.tensor(y), cfg)
+        assert abs(L - tL) < 1e-10
+    for k, v in tp.items():
+        np.testing.assert_allclose(v.detach().numpy(), p[k], rtol=1e-8, atol=1e-11, err_msg=k)
