@@ -5,6 +5,9 @@ SRC   := cffm_amd/csrc
 OUT   := cffm_amd/lib
 OBJS  := $(patsubst $(SRC)/%.hip,build/%.o,$(wildcard $(SRC)/*.hip))
 CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function -Wno-unused-variable
+ifdef PHASE_TIMERS
+CXXFLAGS += -DCFFM_PHASE_TIMERS
+endif
 
 all: $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so
 

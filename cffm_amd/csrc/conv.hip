@@ -577,6 +577,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 //                   read straight from L2 as 16-byte pieces (no LDS, no barrier at all for L0 = false).
 // =================================================================================================
 // rows [m0, m0 + 16*RM) clipped to m_hi (the fused forward kernel passes the rows of ONE example)
+#ifdef CFFM_PHASE_TIMERS
+// debug build only (make PHASE_TIMERS=1): 100 MHz timestamps of workgroup 7's phase boundaries
+__device__ unsigned long long cffm_phase_times[16];
+#define PHASE_MARK(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[i] = wall_clock64(); } while (0)
+#define PHASE_MARK2(i) do { if (a.lgSo == 3 && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
+extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(cffm_phase_times), sizeof(cffm_phase_times));
+}
+#else
+#define PHASE_MARK(i) do {} while (0)
+#define PHASE_MARK2(i) do {} while (0)
+#endif
+
 template <int NT, int RM, bool GEN>
 __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0, int64_t m_hi, char* smem) {
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
@@ -588,6 +601,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
     const int b0 = (int)(m0 >> (2 * a.lgSo));
 
+    PHASE_MARK2(0);
     // ---- issue every global load of this wave ----------------------------------------------------------
     float4 wv[NW4];
     const float4* wsrc = reinterpret_cast<const float4*>(a.W + tap * PP * PP);
@@ -618,6 +632,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
         *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[i];
     }
     __syncthreads();
+    PHASE_MARK2(1);
     if (GEN) {
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
@@ -644,6 +659,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
                 av[rm][h].z = act_pos(av[rm][h].z, a.act); av[rm][h].w = act_pos(av[rm][h].w, a.act);
             }
     }
+    PHASE_MARK2(2);
     // ---- MFMA: K = PP channels of this tap -----------------------------------------------------------------
     f32x4 acc[RM][NT];
 #pragma unroll
@@ -667,7 +683,9 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
         }
     }
     // ---- sum the four taps (fixed order) and write relu(conv + bias) ------------------------------------------
+    PHASE_MARK2(3);
     __syncthreads();                                           // every wave is done with its W quarter
+    PHASE_MARK2(4);
     f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RM*NT tiles][64 lanes]
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
@@ -688,6 +706,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
             if (m < m_hi) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
         }
     }
+    PHASE_MARK2(5);
 }
 
 template <int NT, int RM, bool GEN>
@@ -945,19 +964,56 @@ struct FwdAllArgs {
     int live, n_rows, id_bits, B;
 };
 
+
+// Stable sort of the B*F sparse-update keys (id << 32 | slot) without a sort: the keys are unique, so the place of a key
+// is the number of keys below it.  The workgroup of example b places its own F keys - n*F/256 compares per thread,
+// every workgroup in parallel, no extra launch and no serial tail.
+#define RANK_MAXF 12
+__device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, int n, int b, int F,
+                                               unsigned long long* __restrict__ out, char* smem) {
+    float* cnt = reinterpret_cast<float*>(smem);              // [4 waves][RANK_MAXF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long mine[RANK_MAXF];
+#pragma unroll
+    for (int f = 0; f < RANK_MAXF; ++f) {
+        const int slot = b * F + (f < F ? f : 0);
+        mine[f] = f < F ? (((unsigned long long)(unsigned)ids[slot] << 32) | (unsigned)slot) : 0ull;
+    }
+    int c[RANK_MAXF];
+#pragma unroll
+    for (int f = 0; f < RANK_MAXF; ++f) c[f] = 0;
+    for (int j = tid; j < n; j += 256) {
+        const unsigned long long kj = ((unsigned long long)(unsigned)ids[j] << 32) | (unsigned)j;
+#pragma unroll
+        for (int f = 0; f < RANK_MAXF; ++f) c[f] += kj < mine[f] ? 1 : 0;
+    }
+#pragma unroll
+    for (int f = 0; f < RANK_MAXF; ++f) {
+        const float t = wave_sum((float)c[f]);               // counts <= 4096: exact in fp32
+        if (lane == 0) cnt[wave * RANK_MAXF + f] = t;
+    }
+    __syncthreads();
+    if (tid < F) {
+        const int rank = (int)(cnt[tid] + cnt[RANK_MAXF + tid] + cnt[2 * RANK_MAXF + tid] + cnt[3 * RANK_MAXF + tid]);
+        const int slot = b * F + tid;
+        out[rank] = ((unsigned long long)(unsigned)ids[slot] << 32) | (unsigned)slot;
+    }
+    __syncthreads();
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void fwd_all_kernel(FwdAllArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
-    if (b == fa.B) {                                   // the extra workgroup: stable sort of the sparse-update keys
-        small_sort_body(nullptr, fa.ids, fa.keys_sorted, fa.n_rows, fa.id_bits, smem);
-        return;
-    }
+    rank_keys_body(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
+    PHASE_MARK(0);
     inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b, inner_out[b]
     __syncthreads();
+    PHASE_MARK(1);
     conv0_fact_fwd_body<NT>(fa.conv[0], b, smem);      // reads Eo[b] (written above), writes C_0[b]
     for (int l = 1; l < fa.live; ++l) {
         __syncthreads();
+        PHASE_MARK(1 + l);
         const ConvArgs& ca = fa.conv[l];
         const int64_t rows = 1ll << (2 * ca.lgSo), m_lo = (int64_t)b * rows, m_hi = m_lo + rows;
         if (rows >= 64) {
@@ -972,7 +1028,9 @@ __global__ __launch_bounds__(256) void fwd_all_kernel(FwdAllArgs fa) {
         }
     }
     __syncthreads();
+    PHASE_MARK(1 + fa.live);
     head_fwd_body(fa.head, b, smem);
+    PHASE_MARK(2 + fa.live);
 }
 
 // conv0_fact_bwd: the whole backward of layer 0 in factorised form (S = 16, small Pp), one workgroup per
@@ -2008,14 +2066,14 @@ extern "C" int cffm_conv_bwd(const cffm_shape_t* s, const float* theta, void* ws
 // ---- fused forward (one launch) --------------------------------------------------------------------------------------
 bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B) {
     const Geo g = make_geo(s);
-    return s->inner_conv && s->outer_conv && g.Pp <= 64 && conv0_fact_ok(g) && (int64_t)B * s->F <= 4096;
+    return s->inner_conv && s->outer_conv && g.Pp <= 64 && conv0_fact_ok(g) && (int64_t)B * s->F <= 4096 && s->F <= RANK_MAXF;
 }
 
 template <int NT>
 static int launch_fwd_all(const FwdAllArgs& fa, size_t lds, hipStream_t st) {
     int rc = set_lds(fwd_all_kernel<NT>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((fwd_all_kernel<NT>), dim3(fa.B + 1), dim3(256), lds, st, fa);
+    hipLaunchKernelGGL((fwd_all_kernel<NT>), dim3(fa.B), dim3(256), lds, st, fa);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -2072,7 +2130,6 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
     if (l_fact > lds) lds = l_fact;
     if (l_taps > lds) lds = l_taps;
     if (head_fwd_lds(g) > lds) lds = head_fwd_lds(g);
-    if ((size_t)SMALL_SORT_LDS > lds) lds = SMALL_SORT_LDS;
     int rc = 0;
     DISPATCH_NT4(PP / 16, rc = (launch_fwd_all<NT_>(fa, lds, st)));
     return rc;
