@@ -1317,9 +1317,8 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
 // the field, in pair order: bitwise reproducible, and ~100x cheaper than ds_add_f32 (measured: the atomic
 // version spent 83 K LDS cycles per CU).
 template <int NT, int RM, bool L0, int HALVES>
-__global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
+__device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem) {
     constexpr int PP = NT * 16, BM = 16 * RM, NTH = 256 * HALVES, NCOPY = 4 * HALVES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2, r = lane & 15, kk = lane >> 4;
@@ -1327,7 +1326,7 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
     const int mtiles = rows_per_wg / BM;
-    const int64_t wg_m0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t wg_m0 = (int64_t)wg * rows_per_wg;
     const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
     const int exsz = a.F * Dp;
     const bool fast = L0 && RM == 4 && a.lgSo >= 4 && a.lgSo <= 6;      // tiles per y = So/16 divides RM
@@ -1539,6 +1538,12 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
     }
 }
 
+template <int NT, int RM, bool L0, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    dgrad_taps_body<NT, RM, L0, HALVES>(a, blockIdx.x, smem);
+}
+
 // wgrad_taps: wave t accumulates the [PP x PP] weight-gradient block of tap t over its share of the
 // workgroup's chunk of rows.  The dC rows of a sub-chunk (<= WGT_SUB rows) are staged ONCE into LDS with
 // 16-byte loads and shared by all taps (B' fragments = conflict-free ds_read_b32: the row pitch PP = 16 mod 32
@@ -1547,9 +1552,8 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 // sub-chunk is cut in two and the two partial blocks of a tap are added (lower half first) through LDS.
 #define WGT_SUB 256
 template <int NT, bool GEN, int HALVES>
-__global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, int nslab, char* smem) {
     constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);               // [WGT_SUB][PP]
     uint32_t* lut = reinterpret_cast<uint32_t*>(Bs + WGT_SUB * PP);   // GEN: [PP]
     float* Es = reinterpret_cast<float*>(lut + (GEN ? PP : 0));       // GEN: [n_ex][F][Dp] of the sub-chunk's examples
@@ -1558,8 +1562,7 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
     const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
     const int n_ex_max = GEN ? WGT_SUB / S2 + 2 : 0;
     f32x4* red = reinterpret_cast<f32x4*>(Es + (GEN ? (n_ex_max * a.F * Dp + 7) / 4 * 4 : 0));   // HALVES == 2
-    const int slab = blockIdx.x;
-    const int64_t rows_per_slab = ((a.Mtot + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+    const int64_t rows_per_slab = ((a.Mtot + nslab - 1) / nslab + 3) / 4 * 4;
     const int64_t m_lo = slab * rows_per_slab, m_hi = min(a.Mtot, m_lo + rows_per_slab);
 
     f32x4 acc[NT][NT];
@@ -1693,6 +1696,22 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
             if (kk == 0) a.slabB[(int64_t)slab * a.slabB_stride + q * 16 + r] = v;
         }
     }
+}
+
+template <int NT, bool GEN, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_taps_body<NT, GEN, HALVES>(a, blockIdx.x, gridDim.x, smem);
+}
+
+// Backward of one conv layer l >= 1 in ONE launch: the input gradient (workgroups [0, n_d)) and the weight/bias
+// gradient (workgroups [n_d, n_d + n_w)) only share their inputs, so the two roles run side by side on the chip
+// instead of back to back - one launch, one cold-cache ramp and one drain less per layer.
+template <int NT, int RM>
+__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < n_d) dgrad_taps_body<NT, RM, false, 1>(d, blockIdx.x, smem);
+    else wgrad_taps_body<NT, false, 1>(w, blockIdx.x - n_d, n_w, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1885,6 +1904,18 @@ static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
     return 0;
 }
 
+template <int NT, int RM>
+static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl, hipStream_t st) {
+    constexpr int BM = 16 * RM;
+    const int n_d = (int)((d.Mtot + BM - 1) / BM);
+    const size_t lds = (size_t)(WGT_SUB * NT * 16) * 4 + 16;
+    int rc = set_lds(conv_bwd_pair_kernel<NT, RM>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM>), dim3(n_d + nsl), dim3(256), lds, st, d, w, n_d, nsl);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline int64_t layer_rows(const Geo& g, int B, int l, int* lgSo) {
     const int So = g.D >> (l + 1);
     *lgSo = ilog2_i(So);
@@ -1972,6 +2003,32 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         float* slabW = gpart + sr.base;
         DISPATCH_NT4(g.Pp / 16, rc = (launch_conv0_fact_bwd<NT_>(a, slabW, slabW + (tl.conv_b[0] - tl.conv_w[0]), sr.len, sr.nslab, st)));
         return rc;
+    }
+    if (which == 3 && l >= 1 && g.Pp <= 64) {
+        int lg;
+        const int64_t Mtot = layer_rows(g, B, l, &lg);
+        if ((Mtot + sr.nslab - 1) / sr.nslab < 128) {          // the 256-thread weight-gradient variant: pair it up
+            WgradArgs wa;
+            wa.in = (const float*)(w + wl.C[l - 1]);
+            wa.dC = (const float*)(w + wl.dC[l]);
+            wa.slabW = gpart + sr.base; wa.slabB = wa.slabW + (tl.conv_b[l] - tl.conv_w[l]);
+            wa.slab_stride = sr.len; wa.slabB_stride = sr.len;
+            wa.Mtot = Mtot; wa.lgSo = lg;
+            wa.B = B; wa.P = g.P; wa.Pp = g.Pp; wa.F = g.F; wa.D = g.D; wa.act = g.act; wa.qblocks = 0;
+            DgradArgs da;
+            da.dC = wa.dC;
+            da.W = theta + tl.conv_w[l];
+            da.Cprev = wa.in;
+            da.dt1 = (const float*)(w + wl.dt1);
+            da.dprev = (float*)(w + wl.dC[l - 1]);
+            da.Mtot = Mtot; da.lgSo = lg;
+            da.B = B; da.P = g.P; da.Pp = g.Pp; da.F = g.F; da.D = g.D; da.act = g.act;
+            da.t1w = 2 * g.D - 2; da.t1off = t1_offset(g, l);
+            const int64_t wg16 = (Mtot + 15) / 16;
+            if (wg16 >= 2 * 512) { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 2>(da, wa, sr.nslab, st))); }
+            else { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 1>(da, wa, sr.nslab, st))); }
+            return rc;
+        }
     }
     if (which & 1) {   // weight / bias gradient
         WgradArgs a;
