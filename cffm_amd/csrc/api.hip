@@ -148,7 +148,7 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
 // backward through the slab reduction; fused = single-GPU step (local loss sum, Adagrad folded into the reduction)
 static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
                          int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream,
-                         bool unscaled = false) {
+                         bool unscaled = false, bool skip_reduce = false) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -161,12 +161,17 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
         if (e != hipSuccess) return (int)e;
     }
     if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, stream, unscaled))) return rc;
+    bool inner_done = false;
     if (s->outer_conv) {
-        for (int l = g.live - 1; l >= 1; --l)
-            if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
+        for (int l = g.live - 1; l >= 1; --l) {
+            if (l == g.live - 1) rc = cffm_conv_bwd_with_inner(s, theta, ws, B, l, stream, &inner_done);
+            else rc = cffm_conv_bwd(s, theta, ws, B, l, stream);
+            if (rc) return rc;
+        }
         if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
     }
-    if ((rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
+    if (!inner_done && (rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
+    if (skip_reduce) return 0;                  // the caller reduces the slabs together with the table update
     return cffm_reduce_slabs_impl(s, ws, B, grad, fused ? theta : nullptr, fused ? theta_acc : nullptr, s->lr, stream);
 }
 
@@ -212,9 +217,8 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
     }
     if (cffm_fwd_all_ok(s, B)) {                 // small-channel shapes: the whole forward (and the key sort) in one launch
         if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st))) return rc;
-        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
-        return cffm_sparse_apply_impl(s, tab, tab_acc, (int64_t)B * s->F, (const float*)(w + wl.dEi),
-                                      (const float*)(w + wl.dEo), (const float*)(w + wl.dfb), ws, B, st);
+        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st, false, true))) return rc;
+        return cffm_update_all(s, tab, tab_acc, theta, theta_acc, grad, ws, B, st);
     }
     rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);
     if (rc) return rc;

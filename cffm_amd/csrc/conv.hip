@@ -19,6 +19,8 @@
 // uses the same k permutation, which the contraction does not care about.
 // Channels are padded to Pp = ceil16(P) in every activation tensor so that 16-byte pieces never
 // straddle a row and tiles never straddle a filter tap; padded channels hold zeros.
+#include <cstring>
+
 #include "internal.hpp"
 #include "inner_body.hpp"
 #include "head_body.hpp"
@@ -1704,14 +1706,18 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
     wgrad_taps_body<NT, GEN, HALVES>(a, blockIdx.x, gridDim.x, smem);
 }
 
-// Backward of one conv layer l >= 1 in ONE launch: the input gradient (workgroups [0, n_d)) and the weight/bias
-// gradient (workgroups [n_d, n_d + n_w)) only share their inputs, so the two roles run side by side on the chip
-// instead of back to back - one launch, one cold-cache ramp and one drain less per layer.
+// Backward of one conv layer l >= 1 in ONE launch: the input gradient (n_d workgroups) and the weight/bias gradient
+// (n_w workgroups) only share their inputs, so the two roles run side by side on the chip instead of back to back -
+// one launch, one cold-cache ramp and one drain less per layer.  The top layer's launch can also carry the backward
+// of the inner branch (n_i workgroups, first in dispatch order: the longest role), which depends on dL/dout only
+// and would otherwise sit on a mostly idle chip while the small top layers run.
 template <int NT, int RM>
-__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w) {
+__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < n_d) dgrad_taps_body<NT, RM, false, 1>(d, blockIdx.x, smem);
-    else wgrad_taps_body<NT, false, 1>(w, blockIdx.x - n_d, n_w, smem);
+    const int bid = blockIdx.x;
+    if (bid < n_i) inner_bwd_body(ib, bid, n_i, smem);
+    else if (bid < n_i + n_d) dgrad_taps_body<NT, RM, false, 1>(d, bid - n_i, smem);
+    else wgrad_taps_body<NT, false, 1>(w, bid - n_i - n_d, n_w, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1905,13 +1911,17 @@ static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
 }
 
 template <int NT, int RM>
-static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl, hipStream_t st) {
+static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl, const InnerBwdArgs* ib, int n_i, hipStream_t st) {
     constexpr int BM = 16 * RM;
     const int n_d = (int)((d.Mtot + BM - 1) / BM);
-    const size_t lds = (size_t)(WGT_SUB * NT * 16) * 4 + 16;
+    size_t lds = (size_t)(WGT_SUB * NT * 16) * 4 + 16;
+    InnerBwdArgs none;
+    memset(&none, 0, sizeof(none));
+    if (ib && inner_bwd_lds(ib->g) > lds) lds = inner_bwd_lds(ib->g);
     int rc = set_lds(conv_bwd_pair_kernel<NT, RM>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM>), dim3(n_d + nsl), dim3(256), lds, st, d, w, n_d, nsl);
+    hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM>), dim3(n_d + nsl + (ib ? n_i : 0)), dim3(256), lds, st, d, w, n_d, nsl,
+                       ib ? *ib : none, ib ? n_i : 0);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1979,7 +1989,8 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
 
 // which: bit 0 = weight/bias gradient, bit 1 = input gradient (the two only share their inputs, so the fused
 // step runs them on different streams)
-static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st, int which = 3) {
+static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st, int which = 3,
+                        bool* with_inner = nullptr) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -2025,8 +2036,13 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             da.B = B; da.P = g.P; da.Pp = g.Pp; da.F = g.F; da.D = g.D; da.act = g.act;
             da.t1w = 2 * g.D - 2; da.t1off = t1_offset(g, l);
             const int64_t wg16 = (Mtot + 15) / 16;
-            if (wg16 >= 2 * 512) { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 2>(da, wa, sr.nslab, st))); }
-            else { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 1>(da, wa, sr.nslab, st))); }
+            InnerBwdArgs ib;
+            int n_i = 0;
+            const bool inner = with_inner != nullptr && s->inner_conv;
+            if (inner) n_i = fill_inner_bwd_args(s, theta, ws, B, &ib);
+            if (wg16 >= 2 * 512) { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 2>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st))); }
+            else { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 1>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st))); }
+            if (inner && !rc) *with_inner = true;
             return rc;
         }
     }
@@ -2091,6 +2107,12 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
 int cffm_conv_bwd_part(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, int which,
                        hipStream_t st) {
     return conv_bwd_any(s, theta, ws, B, layer, st, which);
+}
+
+int cffm_conv_bwd_with_inner(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st,
+                             bool* inner_done) {
+    *inner_done = false;
+    return conv_bwd_any(s, theta, ws, B, layer, st, 3, inner_done);
 }
 
 extern "C" int cffm_outer_conv0_fwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {

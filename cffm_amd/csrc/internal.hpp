@@ -23,6 +23,14 @@ int cffm_inner_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int
 // one half of a conv layer's backward: which & 1 = weight/bias gradient, which & 2 = input gradient
 int cffm_conv_bwd_part(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, int which,
                        hipStream_t st);
+// fused single-GPU update (both tables branches on): slab reduction + dense Adagrad and the sorted sparse table update
+// as two roles of one launch; the keys must already be sorted in ws.sort_vals
+int cffm_update_all(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc, float* theta,
+                    float* theta_acc, float* grad, void* ws, int32_t B, hipStream_t st);
+// backward of conv layer `layer`; where the paired launch is available it also carries the inner-branch backward
+// (*inner_done = true), which the caller must then not launch again
+int cffm_conv_bwd_with_inner(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st,
+                             bool* inner_done);
 // the two halves of the sparse update: stable sort of the packed keys, then the segment-sum + Adagrad sweep
 int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_rows, void* ws, int32_t B_ws, bool prepacked,
                         hipStream_t st, int64_t id_stride = 1);

@@ -12,10 +12,10 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
-                                                           float* __restrict__ grad, float* __restrict__ theta,
-                                                           float* __restrict__ acc, float lr) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void reduce_slabs_body(int bid, const float* __restrict__ gpart, int64_t n, const SlabPlan& sp,
+                                                  float* __restrict__ grad, float* __restrict__ theta,
+                                                  float* __restrict__ acc, float lr) {
+    const int64_t i = (int64_t)bid * 256 + threadIdx.x;
     if (i >= n) return;
     int hit = 0;
     for (int r = 1; r < sp.n; ++r)
@@ -31,6 +31,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         acc[i] = a;
         theta[i] -= lr * s / sqrtf(a);
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
+                                                           float* __restrict__ grad, float* __restrict__ theta,
+                                                           float* __restrict__ acc, float lr) {
+    reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, theta, acc, lr);
 }
 
 // Late loss normalisation of the data-parallel step: the backward pass ran with dL/dout = (out - y) / Bg, i.e.
@@ -69,14 +75,24 @@ __global__ __launch_bounds__(256) void small_sort_kernel(const unsigned long lon
 }
 
 // one wavefront per sorted position; only segment heads do work
-__global__ __launch_bounds__(256) void sparse_adagrad_kernel(
-    const unsigned long long* __restrict__ keys, int64_t n, int M, int K, int D,
-    const float* __restrict__ dEi, const float* __restrict__ dEo, const float* __restrict__ dfb,
-    float* __restrict__ inner, float* __restrict__ outer, float* __restrict__ fbias,
-    float* __restrict__ a_inner, float* __restrict__ a_outer, float* __restrict__ a_fbias, float lr,
-    int64_t sEi, int64_t sEo, int64_t sfb, LateScale ls) {
-    const float gscale = late_scale(ls);
-    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+struct SparseArgs {
+    const unsigned long long* keys;
+    int64_t n;
+    int M, K, D;
+    const float *dEi, *dEo, *dfb;
+    float *inner, *outer, *fbias, *a_inner, *a_outer, *a_fbias;
+    float lr;
+    int64_t sEi, sEo, sfb;
+    LateScale ls;
+};
+
+__device__ __forceinline__ void sparse_adagrad_body(int bid, const SparseArgs& a) {
+    const unsigned long long* __restrict__ keys = a.keys;
+    const int64_t n = a.n;
+    const int M = a.M, K = a.K, D = a.D;
+    const float* __restrict__ dEi = a.dEi; const float* __restrict__ dEo = a.dEo; const float* __restrict__ dfb = a.dfb;
+    const float gscale = late_scale(a.ls);
+    const int64_t pos = (int64_t)bid * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pos >= n) return;
     const int id = (int)(keys[pos] >> 32);
@@ -92,18 +108,28 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(
                 const unsigned long long kq = keys[q];
                 if ((int)(kq >> 32) != id) break;
                 const int64_t sl = (int64_t)(kq & 0xffffffffull);
-                g += c < Ki ? dEi[sl * sEi + c] : (c < W - 1 ? dEo[sl * sEo + (c - Ki)] : dfb[sl * sfb]);
+                g += c < Ki ? dEi[sl * a.sEi + c] : (c < W - 1 ? dEo[sl * a.sEo + (c - Ki)] : dfb[sl * a.sfb]);
             }
             g *= gscale;
             float *vp, *ap;
-            if (c < Ki) { vp = inner + (int64_t)id * K + c; ap = a_inner + (int64_t)id * K + c; }
-            else if (c < W - 1) { vp = outer + (int64_t)id * D + (c - Ki); ap = a_outer + (int64_t)id * D + (c - Ki); }
-            else { vp = fbias + id; ap = a_fbias + id; }
-            const float a = *ap + g * g;
-            *ap = a;
-            *vp -= lr * g / sqrtf(a);
+            if (c < Ki) { vp = a.inner + (int64_t)id * K + c; ap = a.a_inner + (int64_t)id * K + c; }
+            else if (c < W - 1) { vp = a.outer + (int64_t)id * D + (c - Ki); ap = a.a_outer + (int64_t)id * D + (c - Ki); }
+            else { vp = a.fbias + id; ap = a.a_fbias + id; }
+            const float acc = *ap + g * g;
+            *ap = acc;
+            *vp -= a.lr * g / sqrtf(acc);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sparse_adagrad_kernel(SparseArgs a) { sparse_adagrad_body(blockIdx.x, a); }
+
+// The two halves of the update do not depend on each other (dense slabs vs table rows): one launch, two roles.
+__global__ __launch_bounds__(256) void update_all_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
+                                                         float* __restrict__ grad, float* __restrict__ theta,
+                                                         float* __restrict__ acc, float lr, int n_reduce, SparseArgs sa) {
+    if ((int)blockIdx.x < n_reduce) reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, theta, acc, lr);
+    else sparse_adagrad_body(blockIdx.x - n_reduce, sa);
 }
 
 extern "C" int cffm_reduce_slabs(const cffm_shape_t* s, void* ws, int32_t B, float* grad, void* stream) {
@@ -185,6 +211,20 @@ int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_row
     return e == hipSuccess ? 0 : (int)e;
 }
 
+static void fill_sparse_args(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
+                             const float* dEi, int64_t sEi, const float* dEo, int64_t sEo, const float* dfb, int64_t sfb,
+                             void* ws, int32_t B_ws, LateScale ls, SparseArgs* out) {
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B_ws, &wl);
+    SparseArgs& a = *out;
+    a.keys = (const unsigned long long*)((char*)ws + wl.sort_vals);
+    a.n = n_rows; a.M = s->M; a.K = s->K; a.D = s->D;
+    a.dEi = dEi; a.dEo = dEo; a.dfb = dfb;
+    a.inner = tab->inner_emb; a.outer = tab->outer_emb; a.fbias = tab->feat_bias;
+    a.a_inner = acc->inner_emb; a.a_outer = acc->outer_emb; a.a_fbias = acc->feat_bias;
+    a.lr = s->lr; a.sEi = sEi; a.sEo = sEo; a.sfb = sfb; a.ls = ls;
+}
+
 int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
                            const float* dEi, const float* dEo, const float* dfb, void* ws, int32_t B_ws, hipStream_t st) {
     LateScale ls = {nullptr, 0.f, 0};
@@ -197,10 +237,29 @@ int cffm_sparse_apply_strided(const cffm_shape_t* s, const cffm_tables_t* tab, c
     if (n_rows <= 0) return 0;
     cffm_ws_layout_t wl;
     cffm_ws_layout(s, B_ws, &wl);
-    const unsigned long long* keys_out = (const unsigned long long*)((char*)ws + wl.sort_vals);
-    hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, keys_out, n_rows,
-                       s->M, s->K, s->D, dEi, dEo, dfb, tab->inner_emb, tab->outer_emb, tab->feat_bias,
-                       acc->inner_emb, acc->outer_emb, acc->feat_bias, s->lr, sEi, sEo, sfb, ls);
+    SparseArgs a;
+    fill_sparse_args(s, tab, acc, n_rows, dEi, sEi, dEo, sEo, dfb, sfb, ws, B_ws, ls, &a);
+    hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// fused single-GPU update: slab reduction + dense Adagrad and the sparse table update in one launch
+int cffm_update_all(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc, float* theta,
+                    float* theta_acc, float* grad, void* ws, int32_t B, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const int64_t n_rows = (int64_t)B * s->F;
+    LateScale ls = {nullptr, 0.f, 0};
+    SparseArgs a;
+    fill_sparse_args(s, tab, tab_acc, n_rows, (const float*)(w + wl.dEi), s->K, (const float*)(w + wl.dEo), s->D,
+                     (const float*)(w + wl.dfb), 1, ws, B, ls, &a);
+    const int n_reduce = (int)((tl.n + 255) / 256);
+    hipLaunchKernelGGL(update_all_kernel, dim3((unsigned)(n_reduce + (n_rows + 3) / 4)), dim3(256), 0, st,
+                       (const float*)(w + wl.gpart), (int64_t)tl.n, sp, grad, theta, theta_acc, s->lr, n_reduce, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
