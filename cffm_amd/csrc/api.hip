@@ -187,7 +187,7 @@ extern "C" int cffm_backward(const cffm_shape_t* s, const float* theta, const fl
 // [B*F][1 + K + D + 1] = (id bits | dEi | dEo | dfb).
 extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta, const int32_t* ids, const float* y,
                                       int32_t B, int64_t B_global, void* ws, float* grad, float* rows, void* stream) {
-    if (s && s->loss == CFFM_LOSS_HYBRID) return CFFM_ERR_UNSUPPORTED;     // two loss sums; single-process only
+    if (s && (s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)) return CFFM_ERR_UNSUPPORTED;   // single-process only
     int rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr,
                            (hipStream_t)stream, true);
     if (rc || B <= 0) return rc;
