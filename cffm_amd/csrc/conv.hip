@@ -1046,29 +1046,30 @@ __global__ __launch_bounds__(256) void fwd_all_kernel(FwdAllArgs fa) {
 //   E  dEj[(dw,j)][x]   = sum_{dh,i<j,q} dT[dh][i][x][q] * W[dh][dw][(i,j)][q]   rows x, k = q, cols (dw,j)
 //   F  dEo[f][h] = dEi[(h&1,f)][h>>1] + dEj[(h&1,f)][h>>1] + ds0[h]*R_f + Q_f  (s0 pool gradient in closed form)
 // ~1640 MFMAs per example against 4608 for the direct wgrad + dgrad, no atomics, fixed summation order.
-template <int NT>
-__global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float* __restrict__ slabW,
+template <int NT, int F_, int D_, int NW>
+__global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, float* __restrict__ slabW,
                                                               float* __restrict__ slabB, int64_t slab_stride) {
-    constexpr int PP = NT * 16, S = 16;
+    constexpr int PP = NT * 16, S = 16, NTH = 64 * NW, XQ = 16 / NW;     // NW wavefronts (4 or 8), XQ x columns per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int F = a.F, D = a.D, Dp = D + 1, P = a.P, F2 = 2 * F;
+    // F_/D_ != 0: the README shapes compiled in, so that the pair indexing, the divisions and the loop bounds fold
+    const int F = F_ ? F_ : a.F, D = D_ ? D_ : a.D, Dp = D + 1, P = F_ ? F_ * (F_ - 1) / 2 : a.P, F2 = 2 * F;
     const int TP = S * PP + 16;
     float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP]
     float* T = Wl + 4 * PP * PP;                                // [2F][TP]   T, later dT
-    float* part = T + 2 * F * TP;                               // [4 waves][16][32] partial tiles (phases B, E)
-    float* dEi = part + 4 * 16 * 32;                            // [32][16]  (n = (dh,i), y)
+    float* part = T + 2 * F * TP;                               // [NW waves][16][32] partial tiles (phases B, E)
+    float* dEi = part + NW * 16 * 32;                            // [32][16]  (n = (dh,i), y)
     float* dEj = dEi + 32 * 16;                                 // [32][16]  (n = (dw,j), x)
-    float* bred = dEj + 32 * 16;                                // [4][PP] bias partials
-    float* rs = bred + 4 * PP;                                  // [F] row sums, [F] dots
+    float* bred = dEj + 32 * 16;                                // [NW][PP] bias partials
+    float* rs = bred + NW * PP;                                  // [F] row sums, [F] dots
     float* Es = rs + 2 * F;                                     // [F][Dp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     float* sw = slabW + (int64_t)blockIdx.x * slab_stride;
     float* sb = slabB + (int64_t)blockIdx.x * slab_stride;
     {
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
-        for (int i = tid; i < 4 * PP * PP / 4; i += 256) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
+        for (int i = tid; i < 4 * PP * PP / 4; i += NTH) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
         // rows of padded pairs (p >= P) are never produced below: they must read as zeros in the reduction
-        for (int e = tid; e < 4 * (PP - P) * PP; e += 256) {
+        for (int e = tid; e < 4 * (PP - P) * PP; e += NTH) {
             const int tap = e / ((PP - P) * PP), o = e - tap * ((PP - P) * PP);
             sw[(tap * PP + P) * PP + o] = 0.f;
         }
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
         {
             const float* e = a.Cprev + (int64_t)b * F * D;      // Eo rows of this example
             const float invD = 1.f / (float)D;
-            for (int i = tid; i < F * D; i += 256) {
+            for (int i = tid; i < F * D; i += NTH) {
                 const int f = fast_div(i, invD), d = i - f * D;
                 Es[f * Dp + d] = e[i];
             }
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
         __syncthreads();
         const float* dCb = a.dC + (int64_t)b * S * S * PP;
         // ---- A: T ----------------------------------------------------------------------------------------------
-        for (int u = wave; u < 2 * (F - 1); u += 4) {
+        for (int u = wave; u < 2 * (F - 1); u += NW) {
             const int i = u % (F - 1), dh = u / (F - 1);
             const int nj = F - 1 - i, K = 2 * nj, base = i * (2 * F - i - 1) / 2;
             f32x4 acc[NT];
@@ -1112,7 +1113,7 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tp[(kk * 4 + j) * PP + nt * 16] = acc[nt][j];
         }
-        for (int e = tid; e < 2 * S * PP; e += 256) {
+        for (int e = tid; e < 2 * S * PP; e += NTH) {
             const int dh = e / (S * PP), o = e - dh * (S * PP);
             T[(dh * F + F - 1) * TP + o] = 0.f;
         }
@@ -1120,15 +1121,15 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
         // ---- B: dEi = dC (rows y) x T^T, this wave's k = its four x -----------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-            float4 av[4][NT];
+            float4 av[XQ][NT];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
+            for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
                 for (int h = 0; h < NT; ++h)
-                    av[q4][h] = *reinterpret_cast<const float4*>(dCb + ((int64_t)r * S + wave + 4 * q4) * PP + 16 * h + 4 * kk);
+                    av[q4][h] = *reinterpret_cast<const float4*>(dCb + ((int64_t)r * S + wave + NW * q4) * PP + 16 * h + 4 * kk);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int x = wave + 4 * q4;
+            for (int q4 = 0; q4 < XQ; ++q4) {
+                const int x = wave + NW * q4;
 #pragma unroll
                 for (int h = 0; h < NT; ++h) {
                     float4 bv[2];
@@ -1153,8 +1154,10 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
                 for (int j = 0; j < 4; ++j) part[(wave * 16 + kk * 4 + j) * 32 + ct * 16 + r] = acc[ct][j];
         }
         __syncthreads();
-        for (int e = tid; e < 16 * 32; e += 256) {               // e = y * 32 + n
-            const float v = ((part[e] + part[512 + e]) + part[1024 + e]) + part[1536 + e];
+        for (int e = tid; e < 16 * 32; e += NTH) {               // e = y * 32 + n
+            float v = part[e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += part[512 * w + e];
             dEi[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();                                          // T fully consumed: phase C may overwrite it
@@ -1169,8 +1172,8 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
                     av[rt][s4] = m < F2 ? Es[i * Dp + 2 * (4 * s4 + kk) + dh] : 0.f;
                 }
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int x = wave + 4 * q4;
+            for (int q4 = 0; q4 < XQ; ++q4) {
+                const int x = wave + NW * q4;
                 float bv[4][NT];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
@@ -1208,7 +1211,7 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
                 for (int i = 0; i < F - 1; ++i) {
                     const int nj = F - 1 - i, K = 2 * nj, base = i * (2 * F - i - 1) / 2;
                     for (int rt = 0; rt * 16 < K; ++rt, ++ucount) {
-                        if ((ucount & 3) != wave) continue;
+                        if ((ucount & (NW - 1)) != wave) continue;
                         const int m = rt * 16 + r;
                         const bool okm = m < K;
                         const int dw = (okm && m >= nj) ? 1 : 0, jj = okm ? m - dw * nj : 0;
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
         // ---- E: dEj = dT (rows x) x W^T over this wave's (dh, i) units -------------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-            for (int u = wave; u < 2 * (F - 1); u += 4) {
+            for (int u = wave; u < 2 * (F - 1); u += NW) {
                 const int i = u % (F - 1), dh = u / (F - 1), base = i * (2 * F - i - 1) / 2;
                 const float* ta = T + (dh * F + i) * TP + r * PP + 4 * kk;
                 const float* wrow[2];
@@ -1276,13 +1279,15 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
             rs[tid] = sacc;
         }
         __syncthreads();
-        for (int e = tid; e < 16 * 32; e += 256) {               // e = x * 32 + n
-            const float v = ((part[e] + part[512 + e]) + part[1024 + e]) + part[1536 + e];
+        for (int e = tid; e < 16 * 32; e += NTH) {               // e = x * 32 + n
+            float v = part[e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += part[512 * w + e];
             dEj[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();
         // ---- F -----------------------------------------------------------------------------------------------------
-        for (int e = tid; e < F * D; e += 256) {
+        for (int e = tid; e < F * D; e += NTH) {
             const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
             float R = 0.f, Q = 0.f;
             for (int j = f + 1; j < F; ++j) R += rs[j];
@@ -1302,9 +1307,14 @@ __global__ __launch_bounds__(256) void conv0_fact_bwd_kernel(DgradArgs a, float*
         if (kk == 0) bred[wave * PP + nt * 16 + r] = v;
     }
     __syncthreads();
-    if (tid < PP) sb[tid] = ((bred[tid] + bred[PP + tid]) + bred[2 * PP + tid]) + bred[3 * PP + tid];
+    if (tid < PP) {
+        float v = bred[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += bred[w * PP + tid];
+        sb[tid] = v;
+    }
     if (first) {                                                  // no example for this slab
-        for (int e = tid; e < 4 * PP * PP; e += 256) sw[e] = 0.f;
+        for (int e = tid; e < 4 * PP * PP; e += NTH) sw[e] = 0.f;
     }
 }
 
@@ -1855,11 +1865,20 @@ static inline bool conv0_fact_bwd_ok(const Geo& g) {
 template <int NT>
 static int launch_conv0_fact_bwd(const DgradArgs& a, float* slabW, float* slabB, int64_t stride, int nsl, hipStream_t st) {
     constexpr int PP = NT * 16;
-    const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (16 * PP + 16) + 4 * 16 * 32 + 2 * 32 * 16 + 4 * PP + 2 * a.F +
+    constexpr int NW = 8;
+    const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (16 * PP + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * PP + 2 * a.F +
                                 a.F * (a.D + 1)) * 4 + 16;
-    int rc = set_lds(conv0_fact_bwd_kernel<NT>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((conv0_fact_bwd_kernel<NT>), dim3(nsl), dim3(256), lds, st, a, slabW, slabB, stride);
+#define CFFM_C0B_LAUNCH(FV, DV)                                                                                  \
+    do {                                                                                                         \
+        int rc = set_lds(conv0_fact_bwd_kernel<NT, FV, DV, NW>, lds);                                                \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((conv0_fact_bwd_kernel<NT, FV, DV, NW>), dim3(nsl), dim3(64 * NW), lds, st, a, slabW, slabB, stride); \
+    } while (0)
+    if (NT == 3 && a.F == 10 && a.D == 32) CFFM_C0B_LAUNCH(10, 32);          // frappe        (README.md:28)
+    else if (NT == 1 && a.F == 6 && a.D == 32) CFFM_C0B_LAUNCH(6, 32);       // book-crossing (README.md:20)
+    else if (NT == 1 && a.F == 3 && a.D == 32) CFFM_C0B_LAUNCH(3, 32);       // ml-tag        (README.md:24)
+    else CFFM_C0B_LAUNCH(0, 0);
+#undef CFFM_C0B_LAUNCH
     CFFM_CHECK_LAUNCH();
     return 0;
 }
