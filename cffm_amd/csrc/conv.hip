@@ -1865,7 +1865,7 @@ static inline bool conv0_fact_bwd_ok(const Geo& g) {
 template <int NT>
 static int launch_conv0_fact_bwd(const DgradArgs& a, float* slabW, float* slabB, int64_t stride, int nsl, hipStream_t st) {
     constexpr int PP = NT * 16;
-    constexpr int NW = 8;
+    constexpr int NW = 16;
     const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (16 * PP + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * PP + 2 * a.F +
                                 a.F * (a.D + 1)) * 4 + 16;
 #define CFFM_C0B_LAUNCH(FV, DV)                                                                                  \
