@@ -592,25 +592,33 @@ extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
 #define PHASE_MARK2(i) do {} while (0)
 #endif
 
-template <int NT, int RM, bool GEN>
-__device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0, int64_t m_hi, char* smem) {
+// G groups of four tap-wavefronts (G = 1: 256 threads): group g takes the RM row tiles starting at m0 + g*16*RM; a group
+// whose rows lie beyond m_hi only helps staging the filter and keeps the barriers.
+template <int NT, int RM, bool GEN, int G = 1>
+__device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0_wg, int64_t m_hi, char* smem) {
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
     constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
     float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
     uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
-    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, tap = (tid >> 6) & 3, grp = tid >> 8, r = lane & 15, kk = lane >> 4;
+    const int64_t m0 = m0_wg + (int64_t)grp * BM;
+    const bool work = m0 < m_hi;
     const int So = 1 << a.lgSo, Sin = 2 * So, Dp = a.D + 1, dh = tap >> 1, dw = tap & 1;
     const int b0 = (int)(m0 >> (2 * a.lgSo));
 
     PHASE_MARK2(0);
     // ---- issue every global load of this wave ----------------------------------------------------------
-    float4 wv[NW4];
+    constexpr int NWG = (NW4 + G - 1) / G;                    // this wave's share of the pieces of W[tap]: i = grp + G*ii
+    float4 wv[NWG];
     const float4* wsrc = reinterpret_cast<const float4*>(a.W + tap * PP * PP);
 #pragma unroll
-    for (int i = 0; i < NW4; ++i) wv[i] = wsrc[lane + 64 * i];
+    for (int ii = 0; ii < NWG; ++ii) {
+        const int i = grp + G * ii;
+        wv[ii] = wsrc[lane + 64 * (i < NW4 ? i : 0)];
+    }
     float4 av[RM][NT];
-    if (!GEN) {
+    if (!GEN && work) {
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             int64_t m = m0 + rm * 16 + r;
@@ -620,7 +628,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
 #pragma unroll
             for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(src + 16 * h);
         }
-    } else {
+    } else if (GEN) {
         const int S2 = So * So;
         const int n_ex = BM > S2 ? BM / S2 : 1;
         build_pair_lut(lut, a.F, PP);
@@ -629,13 +637,15 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     // ---- W[tap] -> this wave's LDS quarter ------------------------------------------------------------------
     float* Wt = Wl + tap * (PP * LDW);
 #pragma unroll
-    for (int i = 0; i < NW4; ++i) {
+    for (int ii = 0; ii < NWG; ++ii) {
+        const int i = grp + G * ii;
         const int u = lane + 64 * i, row = u / (PP / 4), c4 = u % (PP / 4);
-        *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[i];
+        if (i < NW4) *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[ii];
     }
     __syncthreads();
     PHASE_MARK2(1);
-    if (GEN) {
+    if (!work) {
+    } else if (GEN) {
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             int64_t m = m0 + rm * 16 + r;
@@ -668,6 +678,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (work)
 #pragma unroll
     for (int h = 0; h < NT; ++h) {
 #pragma unroll
@@ -688,23 +699,24 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     PHASE_MARK2(3);
     __syncthreads();                                           // every wave is done with its W quarter
     PHASE_MARK2(4);
-    f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RM*NT tiles][64 lanes]
+    constexpr int RT = RM * G;                                 // row tiles of the workgroup
+    f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RT*NT tiles][64 lanes]
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) red[(tap * RM * NT + rm * NT + nt) * 64 + lane] = acc[rm][nt];
+        for (int nt = 0; nt < NT; ++nt) red[(tap * RT * NT + (grp * RM + rm) * NT + nt) * 64 + lane] = acc[rm][nt];
     __syncthreads();
-    for (int idx = tid; idx < RM * NT * 64; idx += 256) {
+    for (int idx = tid; idx < RT * NT * 64; idx += 256 * G) {
         const int tile = idx >> 6, ln = idx & 63, rm = tile / NT, nt = tile - rm * NT;
         f32x4 v = red[idx];
-        v += red[RM * NT * 64 + idx];
-        v += red[2 * RM * NT * 64 + idx];
-        v += red[3 * RM * NT * 64 + idx];
+        v += red[RT * NT * 64 + idx];
+        v += red[2 * RT * NT * 64 + idx];
+        v += red[3 * RT * NT * 64 + idx];
         const int n = nt * 16 + (ln & 15);
         const float bv = a.bias[n];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t m = m0 + rm * 16 + (ln >> 4) * 4 + j;
+            const int64_t m = m0_wg + rm * 16 + (ln >> 4) * 4 + j;
             if (m < m_hi) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
         }
     }
@@ -847,9 +859,9 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
 //                             A fragment = one ds_read of E, B fragment = one ds_read of the staged filter.
 //   step 2, wave w owns x = w, w+4, ...: rows y, k = (dh, i), B fragment = T[(dh,i)][x][q] (row pitch padded by
 //                             16 floats so the two k rows of a half-wave hit disjoint banks).
-template <int NT>
+template <int NT, int NW = 4>
 __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem) {
-    constexpr int PP = NT * 16;
+    constexpr int PP = NT * 16, NTH = 64 * NW, XQ = 16 / NW;      // NW wavefronts; step 2 gives each XQ columns at a time
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16;
     const int TP = S * PP + 16;                                 // pitch of one (dh, i) plane of T
     float* Wl = reinterpret_cast<float*>(smem);                // [4*PP][PP]
@@ -858,10 +870,10 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     {   // stage the filter and the embedding tile (one barrier)
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
-        for (int i = tid; i < 4 * PP * PP / 4; i += 256) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
+        for (int i = tid; i < 4 * PP * PP / 4; i += NTH) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
         const float* e = a.in + (int64_t)b * F * D;
         const float invD = 1.f / (float)D;
-        for (int i = tid; i < F * D; i += 256) {
+        for (int i = tid; i < F * D; i += NTH) {
             const int f = fast_div(i, invD), d = i - f * D;
             Es[f * Dp + d] = e[i];
         }
@@ -869,7 +881,7 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
     __syncthreads();
     // ---- step 1: unit (dh, i, rt) with all NT column tiles at once (one A fragment feeds NT MFMAs) ---------------
     const int units = 2 * (F - 1) * RT;
-    for (int u = wave; u < units; u += 4) {
+    for (int u = wave; u < units; u += NW) {
         int t = u;
         const int rt = t % RT; t /= RT;
         const int i = t % (F - 1), dh = t / (F - 1);
@@ -895,7 +907,7 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
             for (int j = 0; j < 4; ++j) tp[(rt * 16 + kk * 4 + j) * PP + nt * 16] = acc[nt][j];
     }
     // planes (dh, F-1) have no pairs: zero them so that step 2 can run a dense k
-    for (int e = tid; e < 2 * S * PP; e += 256) {
+    for (int e = tid; e < 2 * S * PP; e += NTH) {
         const int dh = e / (S * PP), o = e - dh * (S * PP);
         T[(dh * F + F - 1) * TP + o] = 0.f;
     }
@@ -907,10 +919,10 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
     for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias[nt * 16 + r];
     for (int rt = 0; rt < RT; ++rt) {
         const int y = rt * 16 + r;
-        for (int xg = wave * 4; xg < S; xg += 16) {
-            f32x4 acc[4][NT];
+        for (int xg = wave * XQ; xg < S; xg += 16) {
+            f32x4 acc[XQ][NT];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
+            for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[q4][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int s2 = 0; s2 < ks2; ++s2) {
@@ -919,18 +931,18 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
                 const int dh = (ok && k >= F) ? 1 : 0, i = ok ? k - dh * F : 0;
                 const float av = ok ? Es[i * Dp + 2 * y + dh] : 0.f;
                 const float* tb = T + (ok ? k : 0) * TP + xg * PP + r;
-                float bv[4][NT];
+                float bv[XQ][NT];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
+                for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bv[q4][nt] = ok ? tb[q4 * PP + nt * 16] : 0.f;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
+                for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[q4][nt] = mfma16(av, bv[q4][nt], acc[q4][nt]);
             }
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
+            for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -971,9 +983,10 @@ struct FwdAllArgs {
 // is the number of keys below it.  The workgroup of example b places its own F keys - n*F/256 compares per thread,
 // every workgroup in parallel, no extra launch and no serial tail.
 #define RANK_MAXF 12
+template <int NW>
 __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, int n, int b, int F,
                                                unsigned long long* __restrict__ out, char* smem) {
-    float* cnt = reinterpret_cast<float*>(smem);              // [4 waves][RANK_MAXF]
+    float* cnt = reinterpret_cast<float*>(smem);              // [NW waves][RANK_MAXF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long mine[RANK_MAXF];
 #pragma unroll
@@ -984,7 +997,7 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
     int c[RANK_MAXF];
 #pragma unroll
     for (int f = 0; f < RANK_MAXF; ++f) c[f] = 0;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += 64 * NW) {
         const unsigned long long kj = ((unsigned long long)(unsigned)ids[j] << 32) | (unsigned)j;
 #pragma unroll
         for (int f = 0; f < RANK_MAXF; ++f) c[f] += kj < mine[f] ? 1 : 0;
@@ -996,43 +1009,51 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
     }
     __syncthreads();
     if (tid < F) {
-        const int rank = (int)(cnt[tid] + cnt[RANK_MAXF + tid] + cnt[2 * RANK_MAXF + tid] + cnt[3 * RANK_MAXF + tid]);
+        float c = cnt[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) c += cnt[w * RANK_MAXF + tid];
+        const int rank = (int)c;
         const int slot = b * F + tid;
         out[rank] = ((unsigned long long)(unsigned)ids[slot] << 32) | (unsigned)slot;
     }
     __syncthreads();
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void fwd_all_kernel(FwdAllArgs fa) {
+// NW wavefronts per workgroup (8 at the README shapes): one example still owns one workgroup, but every SIMD now has
+// two wavefronts to switch between, which is what hides the LDS / MFMA / L2 latencies of the per-example phases.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
+    constexpr int G = NW / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x;
-    rank_keys_body(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
-    PHASE_MARK(0);
-    inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b, inner_out[b]
-    __syncthreads();
-    PHASE_MARK(1);
-    conv0_fact_fwd_body<NT>(fa.conv[0], b, smem);      // reads Eo[b] (written above), writes C_0[b]
-    for (int l = 1; l < fa.live; ++l) {
+    for (int b = blockIdx.x; b < fa.B; b += gridDim.x) {
+        if (b != (int)blockIdx.x) __syncthreads();
+        rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
+        PHASE_MARK(0);
+        inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b, inner_out[b]
         __syncthreads();
-        PHASE_MARK(1 + l);
-        const ConvArgs& ca = fa.conv[l];
-        const int64_t rows = 1ll << (2 * ca.lgSo), m_lo = (int64_t)b * rows, m_hi = m_lo + rows;
-        if (rows >= 64) {
-            for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
-                if (m0 > m_lo) __syncthreads();
-                conv_fwd_taps_body<NT, 4, false>(ca, m0, m_hi, smem);
+        PHASE_MARK(1);
+        conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem);  // reads Eo[b] (written above), writes C_0[b]
+        for (int l = 1; l < fa.live; ++l) {
+            __syncthreads();
+            PHASE_MARK(1 + l);
+            const ConvArgs& ca = fa.conv[l];
+            const int64_t rows = 1ll << (2 * ca.lgSo), m_lo = (int64_t)b * rows, m_hi = m_lo + rows;
+            if (rows >= 64) {
+                for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
+                    if (m0 > m_lo) __syncthreads();
+                    conv_fwd_taps_body<NT, 4 / G, false, G>(ca, m0, m_hi, smem);
+                }
+            } else if (rows >= 32) {
+                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G>(ca, m_lo, m_hi, smem);
+            } else {
+                conv_fwd_taps_body<NT, 1, false, G>(ca, m_lo, m_hi, smem);
             }
-        } else if (rows >= 32) {
-            conv_fwd_taps_body<NT, 2, false>(ca, m_lo, m_hi, smem);
-        } else {
-            conv_fwd_taps_body<NT, 1, false>(ca, m_lo, m_hi, smem);
         }
+        __syncthreads();
+        PHASE_MARK(1 + fa.live);
+        head_fwd_body<NW>(fa.head, b, smem);
+        PHASE_MARK(2 + fa.live);
     }
-    __syncthreads();
-    PHASE_MARK(1 + fa.live);
-    head_fwd_body(fa.head, b, smem);
-    PHASE_MARK(2 + fa.live);
 }
 
 // conv0_fact_bwd: the whole backward of layer 0 in factorised form (S = 16, small Pp), one workgroup per
@@ -1479,7 +1500,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
             }
         }
     }
-    if (L0) {
+    if constexpr (L0) {
         if (fast) {   // x of (rm, kk, j) is the same for every m tile: x = (rm*16 + kk*4 + j) & (So - 1)
             float* tj = Tj + (half * 4 + tap) * PP * So;
 #pragma unroll
@@ -2169,9 +2190,10 @@ bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B) {
 
 template <int NT>
 static int launch_fwd_all(const FwdAllArgs& fa, size_t lds, hipStream_t st) {
-    int rc = set_lds(fwd_all_kernel<NT>, lds);
+    constexpr int NW = 8;
+    int rc = set_lds(fwd_all_kernel<NT, NW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((fwd_all_kernel<NT>), dim3(fa.B), dim3(256), lds, st, fa);
+    hipLaunchKernelGGL((fwd_all_kernel<NT, NW>), dim3(fa.B < 256 ? fa.B : 256), dim3(64 * NW), lds, st, fa);
     CFFM_CHECK_LAUNCH();
     return 0;
 }

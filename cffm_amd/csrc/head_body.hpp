@@ -34,7 +34,11 @@ __device__ __forceinline__ float loss_term(float out_raw, float y, int loss, flo
 #define HEAD_KPP 16      // preloaded dense(32) rows per thread: covers 2D-2 <= 128
 static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFFM_HEAD_UNITS + CFFM_MAX_FIELDS + 4 + g.F * g.D) * 4 + 16; }
 
+// NW wavefronts: the pooling sweeps, the embedding tile and s0 use all of them; the dense(32) partials stay on the
+// first 256 threads (8 parts x 32 units)
+template <int NW = 4>
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem) {
+    constexpr int NTH = 64 * NW, RPW = 16 / NW;                    // rows per wave in one pooling sweep
     float* t1s = reinterpret_cast<float*>(smem);                   // [1024]
     float (*hpart)[CFFM_HEAD_UNITS] = reinterpret_cast<float (*)[CFFM_HEAD_UNITS]>(t1s + 1024);   // [8][32]
     float* rs = t1s + 1024 + 8 * CFFM_HEAD_UNITS;                  // [CFFM_MAX_FIELDS]
@@ -47,7 +51,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     // ---- phase 0: independent loads ------------------------------------------------------------------------
     float w1r[HEAD_KPP];
     const bool pre = a.outer_conv && kpp <= HEAD_KPP;
-    if (pre) {
+    if (pre && tid < 256) {
 #pragma unroll
         for (int i = 0; i < HEAD_KPP; ++i) {
             const int k = part * kpp + i;
@@ -58,7 +62,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     if (wave == 1 && lane < g.F) fbv = a.fb[(int64_t)b * g.F + lane];
     if (a.outer_conv) {
         const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
-        for (int i = tid; i < g.F * g.D / 4; i += 256) reinterpret_cast<float4*>(Et)[i] = E4[i];
+        for (int i = tid; i < g.F * g.D / 4; i += NTH) reinterpret_cast<float4*>(Et)[i] = E4[i];
     }
     float o = 0.f;
     if (a.outer_conv) {
@@ -70,11 +74,13 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             const float4* base = reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);
             // wave w owns rows w, w+4, ...; four rows are swept together so that four loads are in flight per lane
             for (int y0 = wave; y0 < S; y0 += 16) {
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};
+                float s4[RPW];
+#pragma unroll
+                for (int u = 0; u < RPW; ++u) s4[u] = 0.f;
                 for (int i = lane; i < n4; i += 64) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int yy = y0 + 4 * u;
+                    for (int u = 0; u < RPW; ++u) {
+                        const int yy = y0 + NW * u;
                         if (yy < S) {
                             const float4 v = base[(int64_t)yy * n4 + i];
                             s4[u] += (act_pos(v.x, g.act) + act_pos(v.y, g.act)) + (act_pos(v.z, g.act) + act_pos(v.w, g.act));
@@ -82,15 +88,15 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RPW; ++u) {
                     const float t = wave_sum(s4[u]);
-                    if (lane == 0 && y0 + 4 * u < S) t1s[off + y0 + 4 * u] = t;
+                    if (lane == 0 && y0 + NW * u < S) t1s[off + y0 + NW * u] = t;
                 }
             }
             off += S;
         }
         __syncthreads();                                             // Et (and the pools) are in LDS
-        for (int f = wave; f < g.F; f += 4) {                       // row sums of the embedding tile
+        for (int f = wave; f < g.F; f += NW) {                      // row sums of the embedding tile
             float s = 0.f;
             for (int d = lane; d < g.D; d += 64) s += Et[f * g.D + d];
             s = wave_sum(s);
@@ -98,7 +104,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         }
         __syncthreads();
         // s0[h] = sum_{w,p} Eo[i_p][h] * Eo[j_p][w] = sum_i Eo[i][h] * sum_{j>i} rowsum(j)   (:381)
-        for (int h = tid; h < g.D; h += 256) {
+        for (int h = tid; h < g.D; h += NTH) {
             float s = 0.f, R = 0.f;
             for (int i = g.F - 2; i >= 0; --i) {
                 R += rs[i + 1];
@@ -107,8 +113,8 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             t1s[h] = s;
         }
         __syncthreads();
-        for (int k = tid; k < t1w; k += 256) a.t1[(int64_t)b * t1w + k] = t1s[k];
-        {                                                            // dense(32), :409: 8 partial sums per unit
+        for (int k = tid; k < t1w; k += NTH) a.t1[(int64_t)b * t1w + k] = t1s[k];
+        if (tid < 256) {                                             // dense(32), :409: 8 partial sums per unit
             float s = 0.f;
             if (pre) {
 #pragma unroll

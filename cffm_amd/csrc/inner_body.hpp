@@ -43,7 +43,7 @@ struct InnerFwdArgs {
     float* inner_out;
     FusedGather fg;
 };
-static inline size_t inner_fwd_lds(const Geo& g) { return (size_t)(g.F * g.K + g.Pp + 8) * 4; }
+static inline size_t inner_fwd_lds(const Geo& g) { return (size_t)(g.F * g.K + g.Pp + 16) * 4; }   // + up to 16 wavefront partials
 
 __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, char* smem) {
     const Geo& g = ia.g;
