@@ -32,7 +32,7 @@ __device__ __forceinline__ float loss_term(float out_raw, float y, int loss, flo
 // embedding tile, this thread's slice of the dense(32) kernel, the first-order inputs), so the kernel pays the
 // L2/HBM latency once instead of once per phase; the pooling sweep keeps four rows in flight per lane.
 #define HEAD_KPP 16      // preloaded dense(32) rows per thread: covers 2D-2 <= 128
-static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFFM_HEAD_UNITS + CFFM_MAX_FIELDS + 4 + g.F * g.D) * 4 + 16; }
+static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFFM_HEAD_UNITS + CFFM_MAX_FIELDS + 4 + g.F * g.D + g.F * g.F) * 4 + 16; }
 
 // NW wavefronts: the pooling sweeps, the embedding tile and s0 use all of them; the dense(32) partials stay on the
 // first 256 threads (8 parts x 32 units)
@@ -44,6 +44,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     float* rs = t1s + 1024 + 8 * CFFM_HEAD_UNITS;                  // [CFFM_MAX_FIELDS]
     float* sc = rs + CFFM_MAX_FIELDS;                              // [4]
     float* Et = sc + 4;                                            // [F][D] embedding tile of this example
+    float* aW = Et + a.g.F * a.g.D;                                // [F][F] attention matrix, staged and used by wave 1 only
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t1w = 2 * g.D - 2;
@@ -58,11 +59,51 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             w1r[i] = (i < kpp && k < t1w) ? a.d1_w[k * CFFM_HEAD_UNITS + q] : 0.f;
         }
     }
-    float fbv = 0.f;
-    if (wave == 1 && lane < g.F) fbv = a.fb[(int64_t)b * g.F + lane];
+    // every scalar / per-lane parameter of the later phases is requested now, so that no phase waits on L2 again
+    float fbv = 0.f, attb = 0.f, linw = 0.f, linb = 0.f, d1b = 0.f, d2w = 0.f, d2b = 0.f, io = 0.f, biasv = 0.f, yv = 0.f;
+    if (wave == 1) {
+        if (lane < g.F) {
+            fbv = a.fb[(int64_t)b * g.F + lane];
+            linw = g.linear_att ? a.lin_w[lane] : 0.f;
+            attb = g.linear_att ? a.att_b[lane] : 0.f;
+        }
+        if (g.linear_att) {
+            linb = a.lin_b[0];
+            for (int e = lane; e < g.F * g.F; e += 64) aW[e] = a.att_W[e];
+        }
+    }
+    if (wave == 0) {
+        if (a.outer_conv && lane < CFFM_HEAD_UNITS) { d1b = a.d1_b[lane]; d2w = a.d2_w[lane]; }
+        if (a.outer_conv) d2b = a.d2_b[0];
+        if (tid == 0) {
+            io = a.inner_conv ? a.inner_out[b] : 0.f;
+            biasv = a.bias[0];
+            yv = a.y ? a.y[b] : 0.f;
+        }
+    }
     if (a.outer_conv) {
         const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
         for (int i = tid; i < g.F * g.D / 4; i += NTH) reinterpret_cast<float4*>(Et)[i] = E4[i];
+    }
+    if (wave == 1) {                                                 // first-order term, :422-446 (needs nothing from the other waves)
+        float lin;
+        if (g.linear_att) {
+            float z = attb;
+            for (int gI = 0; gI < g.F; ++gI) {
+                const float fg = __shfl(fbv, gI, 64);
+                if (lane < g.F) z += fg * aW[gI * g.F + lane];          // staged by this wavefront above: no barrier needed
+            }
+            z = lane < g.F ? z / g.lamda_att : -INFINITY;
+            const float mx = wave_max(z);
+            const float e = lane < g.F ? expf(z - mx) : 0.f;
+            const float den = wave_sum(e);
+            const float at = e / den;
+            if (lane < g.F) a.att[(int64_t)b * g.F + lane] = at;
+            lin = wave_sum(lane < g.F ? fbv * at * linw : 0.f) + linb;
+        } else {
+            lin = wave_sum(fbv);
+        }
+        if (lane == 0) sc[1] = lin;
     }
     float o = 0.f;
     if (a.outer_conv) {
@@ -131,45 +172,25 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         if (wave == 0) {                                             // + bias, then dense(1) * beta, :410, :414
             float h = 0.f;
             if (lane < CFFM_HEAD_UNITS) {
-                h = a.d1_b[lane];
+                h = d1b;
 #pragma unroll
                 for (int pp = 0; pp < 8; ++pp) h += hpart[pp][lane];
                 a.h1[(int64_t)b * CFFM_HEAD_UNITS + lane] = h;
             }
-            float v = lane < CFFM_HEAD_UNITS ? h * a.d2_w[lane] : 0.f;
+            float v = lane < CFFM_HEAD_UNITS ? h * d2w : 0.f;
             v = wave_sum(v);
-            if (lane == 0) sc[0] = g.beta_outer * (v + a.d2_b[0]);
+            if (lane == 0) sc[0] = g.beta_outer * (v + d2b);
         }
-    }
-    if (wave == 1) {                                                 // first-order term, :422-446
-        float lin;
-        if (g.linear_att) {
-            float z = lane < g.F ? a.att_b[lane] : 0.f;
-            for (int gI = 0; gI < g.F; ++gI) {
-                const float fg = __shfl(fbv, gI, 64);
-                if (lane < g.F) z += fg * a.att_W[gI * g.F + lane];
-            }
-            z = lane < g.F ? z / g.lamda_att : -INFINITY;
-            const float mx = wave_max(z);
-            const float e = lane < g.F ? expf(z - mx) : 0.f;
-            const float den = wave_sum(e);
-            const float at = e / den;
-            if (lane < g.F) a.att[(int64_t)b * g.F + lane] = at;
-            lin = wave_sum(lane < g.F ? fbv * at * a.lin_w[lane] : 0.f) + a.lin_b[0];
-        } else {
-            lin = wave_sum(fbv);
-        }
-        if (lane == 0) sc[1] = lin;
     }
     __syncthreads();
     if (tid == 0) {
         if (a.outer_conv) o = sc[0];
-        float out = (a.inner_conv ? a.inner_out[b] : 0.f);
+        float out = io;
         out += o;
         out += sc[1];
-        out += a.bias[0];                                            // :449-453
+        out += biasv;                                                // :449-453
         float ev = out;
-        if (a.y) a.sqerr[b] = loss_term(out, a.y[b], a.loss, &ev);
+        if (a.y) a.sqerr[b] = loss_term(out, yv, a.loss, &ev);
         else if (a.loss == CFFM_LOSS_LOG) ev = 1.f / (1.f + expf(-out));
         a.out[b] = ev;
     }
