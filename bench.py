@@ -226,13 +226,17 @@ def main():
                     help='frappe is the contract workload; the others are for profiling')
     ap.add_argument('--tables', default='replicated', choices=['replicated', 'sharded'],
                     help='sharded: row-sharded tables (cffm_amd.dist.ShardedStep), the mode for vocabularies beyond one GPU')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='run the data-parallel step (2 collectives) even at world size 1: what one rank of an N-GPU job executes')
+    ap.add_argument('--graph', action='store_true',
+                    help='data-parallel step as a HIP-graph replay (RCCL collectives captured); eager by default')
     ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    use_pg = world > 1 or args.tables == 'sharded'
+    use_pg = world > 1 or args.tables == 'sharded' or args.force_dp
     if use_pg:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -262,10 +266,10 @@ def main():
         sh = ShardedStep(eng)
         step = lambda i: sh.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: dist.barrier()
-    elif world > 1:
+    elif world > 1 or args.force_dp:
         from cffm_amd.dist import DataParallelStep
         eng = HipEngine(cfg, seed=2021, device=str(device))
-        dp = DataParallelStep(eng)
+        dp = DataParallelStep(eng, use_graph=args.graph)
         step = lambda i: dp.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: dist.barrier()
     else:
@@ -309,7 +313,7 @@ def main():
         res['step_flops'] = {'reference_algorithm_TFLOPs': round(tf, 2), 'mfma_f32_peak_TFLOPs': MFMA_F32_PEAK_TFLOPS * world,
                              'frac': round(tf / (MFMA_F32_PEAK_TFLOPS * world), 4),
                              'note': 'conv0 runs factorised (rank-1 input channels), so executed FLOPs are lower'}
-        if world == 1 and not args.quick and args.tables == 'replicated':
+        if world == 1 and not args.quick and args.tables == 'replicated' and not args.force_dp:
             # the same loop with the host-side batcher of CFFM.train in it (random start on the host, slice of the
             # device-resident split): SURVEY 8d's "second figure including host batching"
             Xall, yall = X.reshape(-1, cfg.F), y.reshape(-1)

@@ -199,6 +199,23 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }
 
+// Local half of a data-parallel step in one call: forward (one launch at the README shapes), backward with
+// dL/dout = (out - y) / B_global, then slab reduction ∥ row packing.  Same outputs as cffm_forward + cffm_backward_unscaled.
+extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                             const float* y, int32_t B, int64_t B_global, void* ws, float* grad, float* rows, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!s->inner_conv || !s->outer_conv || !y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)
+        return CFFM_ERR_UNSUPPORTED;
+    if (cffm_fwd_all_ok(s, B)) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st);
+    else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st);
+    if (rc) return rc;
+    if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, st, true, true))) return rc;
+    return cffm_dp_tail(s, ids, B, ws, grad, rows, st);
+}
+
 extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,
                                float* theta, float* theta_acc, float* grad, const int32_t* ids, const float* y,
                                int32_t B, void* ws, float* loss, void* stream) {

@@ -48,16 +48,126 @@ __device__ __forceinline__ float late_scale(const LateScale& ls) {
     return ls.on ? 1.f / sqrtf(ls.sum[0] * ls.inv_Bg + 1e-10f) : 1.f;
 }
 
-__global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ v, float* __restrict__ acc,
-                                                            const float* __restrict__ grad, int64_t n, float lr,
-                                                            LateScale ls, float* __restrict__ loss_out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void dense_adagrad_body(int bid, float* __restrict__ v, float* __restrict__ acc,
+                                                   const float* __restrict__ grad, int64_t n, float lr, const LateScale& ls,
+                                                   float* __restrict__ loss_out) {
+    const int64_t i = (int64_t)bid * 256 + threadIdx.x;
     if (i == 0 && loss_out != nullptr) loss_out[0] = ls.on ? sqrtf(ls.sum[0] * ls.inv_Bg + 1e-10f) : ls.sum[0] * ls.inv_Bg;
     if (i >= n) return;
     const float g = grad[i] * late_scale(ls);
     const float a = acc[i] + g * g;
     acc[i] = a;
     v[i] -= lr * g / sqrtf(a);
+}
+
+__global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ v, float* __restrict__ acc,
+                                                            const float* __restrict__ grad, int64_t n, float lr,
+                                                            LateScale ls, float* __restrict__ loss_out) {
+    dense_adagrad_body(blockIdx.x, v, acc, grad, n, lr, ls, loss_out);
+}
+
+// Sorted order of n <= 8192 unique keys (id << 32 | slot) without a sort: the place of a key is the number of keys below
+// it.  Workgroup w of nwg places keys [w*kpw, (w+1)*kpw): its 256 threads split the n candidates, count per key in
+// registers, wave/block-reduce, and the first kpw threads store their key at its rank.  ids are read with a stride
+// (the id column of the packed rows of the data-parallel step, or a plain id array with stride 1).
+#define RANK_KPW_MAX 32
+__device__ __forceinline__ void rank_place_body(int wg, int nwg, const int32_t* __restrict__ ids, int64_t id_stride, int n,
+                                                unsigned long long* __restrict__ out, float* cnt /* LDS [4][RANK_KPW_MAX] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kpw = (n + nwg - 1) / nwg, k0 = wg * kpw;
+    unsigned long long mine[RANK_KPW_MAX];
+#pragma unroll
+    for (int k = 0; k < RANK_KPW_MAX; ++k) {
+        const int slot = k0 + k;
+        mine[k] = (k < kpw && slot < n) ? (((unsigned long long)(unsigned)ids[(int64_t)slot * id_stride] << 32) | (unsigned)slot) : 0ull;
+    }
+    int c[RANK_KPW_MAX];
+#pragma unroll
+    for (int k = 0; k < RANK_KPW_MAX; ++k) c[k] = 0;
+    for (int j = tid; j < n; j += 256) {
+        const unsigned long long kj = ((unsigned long long)(unsigned)ids[(int64_t)j * id_stride] << 32) | (unsigned)j;
+#pragma unroll
+        for (int k = 0; k < RANK_KPW_MAX; ++k)
+            if (k < kpw) c[k] += kj < mine[k] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < RANK_KPW_MAX; ++k) {
+        if (k < kpw) {
+            const float t = wave_sum((float)c[k]);               // counts <= 8192: exact in fp32
+            if (lane == 0) cnt[wave * RANK_KPW_MAX + k] = t;
+        }
+    }
+    __syncthreads();
+    if (tid < kpw && k0 + tid < n) {
+        const int rank = (int)(((cnt[tid] + cnt[RANK_KPW_MAX + tid]) + cnt[2 * RANK_KPW_MAX + tid]) + cnt[3 * RANK_KPW_MAX + tid]);
+        const int slot = k0 + tid;
+        out[rank] = ((unsigned long long)(unsigned)ids[(int64_t)slot * id_stride] << 32) | (unsigned)slot;
+    }
+}
+
+// first launch of cffm_dp_apply: dense Adagrad with the late 1/L ∥ placement of the gathered keys
+__global__ __launch_bounds__(256) void dp_head_kernel(float* __restrict__ v, float* __restrict__ acc, const float* __restrict__ grad,
+                                                      int64_t n, float lr, LateScale ls, float* __restrict__ loss_out, int n_dense,
+                                                      const int32_t* __restrict__ ids, int64_t id_stride, int n_keys, int n_rank,
+                                                      unsigned long long* __restrict__ keys_out) {
+    __shared__ float cnt[4 * RANK_KPW_MAX];
+    if ((int)blockIdx.x < n_dense) dense_adagrad_body(blockIdx.x, v, acc, grad, n, lr, ls, loss_out);
+    else rank_place_body(blockIdx.x - n_dense, n_rank, ids, id_stride, n_keys, keys_out, cnt);
+}
+
+// last launch of cffm_dp_local: slab reduction (no update) ∥ packing of (id | dEi | dEo | dfb) rows + the local loss sum
+struct PackArgs {
+    const int32_t* ids;
+    int64_t n_slots;
+    int K, D, B;
+    const float *dEi, *dEo, *dfb, *sqerr;
+    float *sum_dst, *rows, *scalars;
+};
+__device__ __forceinline__ void pack_rows_body(int bid, int nblk, const PackArgs& a, float* red) {
+    const int W = 1 + a.K + a.D + 1;
+    const int64_t total = a.n_slots * W;
+    if (bid == 0) {                                  // loss-term sum of this rank, fixed order
+        float part = 0.f;
+        for (int i = threadIdx.x; i < a.B; i += 256) part += a.sqerr[i];
+        const float sum = block_sum(part, red);
+        if (threadIdx.x == 0) { a.sum_dst[0] = sum; a.scalars[0] = sum; }
+    }
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+        const int64_t slot = i / W;
+        const int c = (int)(i - slot * W);
+        float v;
+        if (c == 0) v = __int_as_float(a.ids[slot]);
+        else if (c <= a.K) v = a.dEi[slot * a.K + (c - 1)];
+        else if (c <= a.K + a.D) v = a.dEo[slot * a.D + (c - 1 - a.K)];
+        else v = a.dfb[slot];
+        a.rows[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void dp_tail_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp, float* __restrict__ grad,
+                                                      int n_reduce, PackArgs pa, int n_pack) {
+    __shared__ float red[4];
+    if ((int)blockIdx.x < n_reduce) reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, nullptr, nullptr, 0.f);
+    else pack_rows_body(blockIdx.x - n_reduce, n_pack, pa, red);
+}
+
+int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws, float* grad, float* rows, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    PackArgs pa;
+    pa.ids = ids; pa.n_slots = (int64_t)B * s->F; pa.K = s->K; pa.D = s->D; pa.B = B;
+    pa.dEi = (const float*)(w + wl.dEi); pa.dEo = (const float*)(w + wl.dEo); pa.dfb = (const float*)(w + wl.dfb);
+    pa.sqerr = (const float*)(w + wl.sqerr); pa.sum_dst = grad + tl.n; pa.rows = rows; pa.scalars = (float*)(w + wl.scalars);
+    const int n_reduce = (int)((tl.n + 255) / 256);
+    const int64_t total = pa.n_slots * (1 + s->K + s->D + 1);
+    int n_pack = (int)((total + 1023) / 1024);
+    if (n_pack > 2048) n_pack = 2048;
+    hipLaunchKernelGGL(dp_tail_kernel, dim3(n_reduce + n_pack), dim3(256), 0, st, (const float*)(w + wl.gpart), (int64_t)tl.n, sp,
+                       grad, n_reduce, pa, n_pack);
+    CFFM_CHECK_LAUNCH();
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restrict__ ids, unsigned long long* keys, int64_t n,
@@ -276,12 +386,24 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
     cffm_theta_layout_t tl;
     cffm_theta_layout(s, &tl);
     LateScale ls = {grad_sum + tl.n, 1.f / (float)B_global, s->loss == CFFM_LOSS_SQUARE_RMSE ? 1 : 0};
-    hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, st, theta, theta_acc,
-                       grad_sum, (int64_t)tl.n, s->lr, ls, loss_out);
-    CFFM_CHECK_LAUNCH();
     const int64_t W = 1 + s->K + s->D + 1;
-    rc = cffm_sort_keys_impl(s, (const int32_t*)rows, n_rows, ws, B_ws, false, st, W);
-    if (rc) return rc;
+    const int n_dense = (int)((tl.n + 255) / 256);
+    if (n_rows > 0 && n_rows <= 8192 && n_rows <= (int64_t)B_ws * s->F) {
+        // dense update and key placement are independent: one launch, two roles
+        cffm_ws_layout_t wl;
+        cffm_ws_layout(s, B_ws, &wl);
+        const int n_rank = 256;                              // kpw = ceil(n_rows / 256) <= 32 keys per workgroup
+        hipLaunchKernelGGL(dp_head_kernel, dim3(n_dense + n_rank), dim3(256), 0, st, theta, theta_acc, grad_sum, (int64_t)tl.n,
+                           s->lr, ls, loss_out, n_dense, (const int32_t*)rows, W, (int)n_rows, n_rank,
+                           (unsigned long long*)((char*)ws + wl.sort_vals));
+        CFFM_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)n_dense), dim3(256), 0, st, theta, theta_acc, grad_sum,
+                           (int64_t)tl.n, s->lr, ls, loss_out);
+        CFFM_CHECK_LAUNCH();
+        rc = cffm_sort_keys_impl(s, (const int32_t*)rows, n_rows, ws, B_ws, false, st, W);
+        if (rc) return rc;
+    }
     return cffm_sparse_apply_strided(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws,
                                      B_ws, ls, st);
 }

@@ -291,6 +291,20 @@ class HipEngine(object):
                                                   self._stream()))
         return self._grad_full, rows
 
+    def dp_local(self, ids, y, B, B_global):
+        """forward + backward_unscaled in one library call (the local half of a data-parallel step)."""
+        ids = self._ids(ids)
+        buf, _ = self.workspace(B)
+        W = 1 + self.cfg.K + self.cfg.D + 1
+        key = ('rows', B)
+        rows = self._ws.get(key)
+        if rows is None:
+            rows = torch.empty((B * self.cfg.F, W), dtype=torch.float32, device=self.device)
+            self._ws[key] = rows
+        hip.check(self.lib.cffm_dp_local(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
+                                         int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(rows), self._stream()))
+        return self._grad_full, rows
+
     def dp_apply(self, grad_full, rows_all, B_global):
         n_rows = rows_all.shape[0]
         B_ws = -(-n_rows // self.cfg.F)

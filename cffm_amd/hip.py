@@ -72,6 +72,7 @@ PROTOTYPES = {
     'cffm_backward': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_backward_unscaled': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, _P]),
+    'cffm_dp_local': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), _P]),
     'cffm_train_step_opt': (C.c_int, [_SH, _TB, _TB, _TB, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),

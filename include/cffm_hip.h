@@ -169,6 +169,10 @@ int cffm_forward(const cffm_shape_t *s, const cffm_tables_t *tab, const float *t
 /* backward half: needs scalars[3] = global loss-term sum (cffm_train_step copies scalars[0] there) */
 int cffm_backward(const cffm_shape_t *s, const float *theta, const float *y, int32_t B, int64_t B_global,
                   void *ws, float *grad, void *stream);
+/* cffm_forward + cffm_backward_unscaled in one call (what one rank runs before the two collectives of a
+ * data-parallel step); uses the single-launch forward where the shape allows */
+int cffm_dp_local(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids, const float *y,
+                  int32_t B, int64_t B_global, void *ws, float *grad, float *rows, void *stream);
 /* Data-parallel halves (cffm_amd/dist.py).  cffm_backward_unscaled = cffm_backward with dL/dout = (out - y) / B_global,
  * i.e. without the 1/L of the RMSE-style loss (CFFM.py:493), which needs the loss-term sum over the GLOBAL batch:
  * grad must hold theta.n + 4 floats, grad[theta.n] receives this rank's loss-term sum so that one all-reduce carries

@@ -332,9 +332,12 @@ def test_data_parallel_halves_on_one_gpu():
     ids = [torch.from_numpy(X[:h]).cuda(), torch.from_numpy(X[h:]).cuda()]
     ys = [torch.from_numpy(y[:h]).cuda(), torch.from_numpy(y[h:]).cuda()]
     grads, rows = [], []
-    for e, i, t in zip(engines, ids, ys):
-        e.forward(i, t)
-        g, r = e.backward_unscaled(i, t, h, B)
+    for k, (e, i, t) in enumerate(zip(engines, ids, ys)):
+        if k == 0:                       # the two routes to the same operands: one library call ...
+            g, r = e.dp_local(i, t, h, B)
+        else:                            # ... or the two halves (what ShardedStep uses around its own lookup)
+            e.forward(i, t)
+            g, r = e.backward_unscaled(i, t, h, B)
         grads.append(g.clone()); rows.append(r.clone())
     torch.cuda.synchronize()
     gsum = grads[0] + grads[1]                       # all-reduce
@@ -351,7 +354,7 @@ def test_data_parallel_halves_on_one_gpu():
         close(loss.cpu().numpy(), [L], 'loss')
         outs.append(e.export_params())
     for k, v in outs[0].items():
-        np.testing.assert_array_equal(v, outs[1][k], err_msg=k)          # replicas stay bit-identical
+        np.testing.assert_array_equal(v, outs[1][k], err_msg=k)          # replicas stay bit-identical (same summed operands)
         extra = None
         if k in grads_ref:
             gk = grads_ref[k].reshape(v.shape)
