@@ -217,6 +217,8 @@ class HipEngine(object):
         if y.dtype != torch.float32 or not y.is_contiguous():
             y = y.to(torch.float32).contiguous()
         B = ids.shape[0]
+        if B == 0:                                   # nothing to learn from: parameters and slots stay as they are
+            return self.loss_buf
         buf, _ = self.workspace(B)
         if self.cfg.optimizer != 'AdagradOptimizer':
             self.opt_step += 1

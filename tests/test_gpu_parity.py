@@ -38,6 +38,9 @@ CASES = {
     'frappe-selu': dict(M=5382, F=10, K=32, D=32, act='selu', B=256),
     'f32-d64-relu': dict(M=4000, F=32, K=64, D=64, act='relu', B=3),
     'f12-d32-nolinatt': dict(M=500, F=12, K=16, D=32, act='selu', B=20, linear_att=0),
+    # batch-size edges of the one-workgroup-per-example kernels: a single example, and B > 256 (workgroup 0 takes two)
+    'b1-elu': dict(M=200, F=6, K=32, D=32, act='elu', B=1),
+    'b257-relu': dict(M=900, F=6, K=32, D=32, act='relu', B=257),
 }
 
 
@@ -95,7 +98,7 @@ def adopt_device_kinks(cfg, eng, B, cache):
     for l in range(cfg.live_layers):
         z = cache['zs'][l]
         kink = np.abs(z) < 1e-5 * np.abs(z).max()
-        assert kink.mean() < 1e-3
+        assert kink.sum() <= max(2, 1e-3 * kink.size)
         if kink.any():
             S = cfg.D >> (l + 1)
             Cg = eng.ws_tensor(B, 'C', (B, S, S, eng.tl.Pp), index=l).cpu().numpy()[..., :cfg.P].astype(np.float64)
@@ -179,7 +182,7 @@ def test_backward_stages(name):
 
 
 @pytest.mark.parametrize('name', ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu',
-                                  'f12-d32-nolinatt'])
+                                  'f12-d32-nolinatt', 'b1-elu', 'b257-relu'])
 @pytest.mark.parametrize('trained_like', [True, False])
 def test_train_step_matches_oracle(name, trained_like):
     """One sess.run((loss, optimizer)): post-update parameters AND Adagrad accumulators of every
@@ -532,3 +535,16 @@ def test_row_sharded_halves_on_one_gpu():
                 u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
                 extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
             close(v, ref.reshape(v.shape), 'rank %d param %s' % (o, k), tol=2e-5, extra=extra)
+
+
+def test_empty_batch_is_a_no_op():
+    cfg, p32, X, y = make_case('tiny-relu')
+    eng = engine_for(cfg, p32)
+    before = eng.export_params()
+    ids = torch.zeros((0, cfg.F), dtype=torch.int32, device='cuda')
+    assert eng.predict(ids).shape == (0,)
+    eng.train_step(ids, torch.zeros(0, device='cuda'))
+    torch.cuda.synchronize()
+    after = eng.export_params()
+    for k, v in before.items():
+        np.testing.assert_array_equal(v, after[k])
