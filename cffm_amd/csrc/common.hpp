@@ -56,6 +56,9 @@ static inline int check_shape(const cffm_shape_t* s) {
 // when it has many rows, 256.  Range r keeps its slabs at gpart + base: [nslab][len] floats.
 // ---------------------------------------------------------------------------------------------
 #define CFFM_NSLAB_SMALL 256
+// slabs of the small ranges (head, inner branch): one per example between 256 and 1024, so that the kernels that walk
+// them (head_bwd, inner_bwd) get one example per workgroup up to B = 1024
+static inline int small_slabs(int32_t B) { return B <= 256 ? 256 : (B >= 1024 ? 1024 : (B + 255) / 256 * 256); }
 struct SlabRange { int64_t off, len, base; int nslab; };
 struct SlabPlan {
     SlabRange r[CFFM_MAX_LAYERS + 3];
@@ -79,12 +82,12 @@ static inline void make_slab_plan(const cffm_shape_t* s, int32_t B, const cffm_t
         return n++;
     };
     const int64_t convs = tl.live > 0 ? tl.conv_w[0] : tl.d1_w;
-    p->head_front = add(0, tl.inner_cw, CFFM_NSLAB_SMALL);
-    p->inner = add(tl.inner_cw, convs, CFFM_NSLAB_SMALL);
+    p->head_front = add(0, tl.inner_cw, small_slabs(B));
+    p->inner = add(tl.inner_cw, convs, small_slabs(B));
     p->conv0 = n;
     for (int l = 0; l < tl.live; ++l)
         add(tl.conv_w[l], l + 1 < tl.live ? tl.conv_w[l + 1] : tl.d1_w, conv_slabs(s, B, l));
-    p->head_back = add(tl.d1_w, tl.n, CFFM_NSLAB_SMALL);
+    p->head_back = add(tl.d1_w, tl.n, small_slabs(B));
     p->n = n;
     p->total = base;
 }

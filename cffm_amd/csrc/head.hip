@@ -254,7 +254,7 @@ int cffm_head_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     a.s_linw = gb + tl.lin_w; a.s_linb = gb + tl.lin_b;
     a.stride_front = rf.len; a.stride_back = rb.len; a.front_len = rf.len; a.back_len = rb.len;
     a.loss = s->loss; a.outer_conv = s->outer_conv; a.unscaled = unscaled ? 1 : 0;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(CFFM_NSLAB_SMALL), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(small_slabs(B)), dim3(256), 0, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
