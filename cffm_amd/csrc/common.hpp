@@ -137,6 +137,17 @@ __device__ __forceinline__ float act_relu_grad(float c, int act) {
     return c > 0.f ? act_grad_f(c, act) : 0.f;
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also drains every
+// outstanding global load and store (vmcnt(0)): a phase that ends with a burst of global stores then pays their full
+// L2 round trip before the next phase may even issue its loads.  With this barrier the stores drain in the background
+// and loads issued before it stay in flight.  Only for barriers that protect LDS data: anything one thread passes to
+// another through GLOBAL memory still needs __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------

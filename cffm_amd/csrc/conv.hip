@@ -594,8 +594,11 @@ extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
 
 // G groups of four tap-wavefronts (G = 1: 256 threads): group g takes the RM row tiles starting at m0 + g*16*RM; a group
 // whose rows lie beyond m_hi only helps staging the filter and keeps the barriers.
+// inL / outL (fused forward only): LDS copies of this example's input / output activations, [rows][PP], rows counted
+// from m_base; the A operand then never touches global memory and the output is left where the next phase reads it.
 template <int NT, int RM, bool GEN, int G = 1>
-__device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0_wg, int64_t m_hi, char* smem) {
+__device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0_wg, int64_t m_hi, char* smem,
+                                                   const float* inL = nullptr, float* outL = nullptr, int64_t m_base = 0) {
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
     constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
     float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
@@ -624,7 +627,8 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
             int64_t m = m0 + rm * 16 + r;
             if (m >= m_hi) m = m_hi - 1;
             const RowPos rp = row_pos(m, a.lgSo);
-            const float* src = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + 4 * kk;
+            const float* src = inL ? inL + ((2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + 4 * kk
+                                   : a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + 4 * kk;
 #pragma unroll
             for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(src + 16 * h);
         }
@@ -642,7 +646,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
         const int u = lane + 64 * i, row = u / (PP / 4), c4 = u % (PP / 4);
         if (i < NW4) *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[ii];
     }
-    __syncthreads();
+    lds_barrier();
     PHASE_MARK2(1);
     if (!work) {
     } else if (GEN) {
@@ -697,7 +701,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     }
     // ---- sum the four taps (fixed order) and write relu(conv + bias) ------------------------------------------
     PHASE_MARK2(3);
-    __syncthreads();                                           // every wave is done with its W quarter
+    lds_barrier();                                           // every wave is done with its W quarter
     PHASE_MARK2(4);
     constexpr int RT = RM * G;                                 // row tiles of the workgroup
     f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RT*NT tiles][64 lanes]
@@ -705,7 +709,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[(tap * RT * NT + (grp * RM + rm) * NT + nt) * 64 + lane] = acc[rm][nt];
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < RT * NT * 64; idx += 256 * G) {
         const int tile = idx >> 6, ln = idx & 63, rm = tile / NT, nt = tile - rm * NT;
         f32x4 v = red[idx];
@@ -717,7 +721,11 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0_wg + rm * 16 + (ln >> 4) * 4 + j;
-            if (m < m_hi) a.out[m * PP + n] = fmaxf(v[j] + bv, 0.f);
+            const float c = fmaxf(v[j] + bv, 0.f);
+            if (m < m_hi) {
+                a.out[m * PP + n] = c;
+                if (outL) outL[(m - m_base) * PP + n] = c;
+            }
         }
     }
     PHASE_MARK2(5);
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
 //   step 2, wave w owns x = w, w+4, ...: rows y, k = (dh, i), B fragment = T[(dh,i)][x][q] (row pitch padded by
 //                             16 floats so the two k rows of a half-wave hit disjoint banks).
 template <int NT, int NW = 4>
-__device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem) {
+__device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem, float* outL = nullptr) {
     constexpr int PP = NT * 16, NTH = 64 * NW, XQ = 16 / NW;      // NW wavefronts; step 2 gives each XQ columns at a time
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16;
     const int TP = S * PP + 16;                                 // pitch of one (dh, i) plane of T
@@ -878,7 +886,7 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
             Es[f * Dp + d] = e[i];
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- step 1: unit (dh, i, rt) with all NT column tiles at once (one A fragment feeds NT MFMAs) ---------------
     const int units = 2 * (F - 1) * RT;
     for (int u = wave; u < units; u += NW) {
@@ -911,7 +919,7 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
         const int dh = e / (S * PP), o = e - dh * (S * PP);
         T[(dh * F + F - 1) * TP + o] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- step 2: a wave takes four x at a time (one A fragment feeds 4*NT MFMAs) ----------------------------------
     const int K2 = 2 * F, ks2 = (K2 + 3) / 4;
     float bias[NT];
@@ -948,7 +956,9 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int yy = rt * 16 + kk * 4 + j;
-                        a.out[(((int64_t)b * S + yy) * S + xg + q4) * PP + nt * 16 + r] = fmaxf(acc[q4][nt][j] + bias[nt], 0.f);
+                        const float c = fmaxf(acc[q4][nt][j] + bias[nt], 0.f);
+                        a.out[(((int64_t)b * S + yy) * S + xg + q4) * PP + nt * 16 + r] = c;
+                        if (outL) outL[(yy * S + xg + q4) * PP + nt * 16 + r] = c;
                     }
         }
     }
@@ -976,6 +986,7 @@ struct FwdAllArgs {
     const int32_t* ids;
     unsigned long long* keys_sorted;
     int live, n_rows, id_bits, B;
+    int c_off[CFFM_MAX_LAYERS];   // byte offsets of the LDS copies of C_l inside the dynamic LDS, -1: activations go through global
 };
 
 
@@ -1023,35 +1034,41 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
 // two wavefronts to switch between, which is what hides the LDS / MFMA / L2 latencies of the per-example phases.
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
-    constexpr int G = NW / 4;
+    constexpr int G = NW / 4, PP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS copies of the conv outputs of this example (fa.c_off[l] >= 0): layer l+1 and the head read them there, the
+    // global copies (needed by the backward) are written behind the LDS-only barriers and drain in the background
+    float* CL[CFFM_MAX_LAYERS];
+#pragma unroll
+    for (int l = 0; l < CFFM_MAX_LAYERS; ++l) CL[l] = fa.c_off[l] >= 0 ? reinterpret_cast<float*>(smem + fa.c_off[l]) : nullptr;
+    const bool lds_act = fa.c_off[0] >= 0;
     for (int b = blockIdx.x; b < fa.B; b += gridDim.x) {
         if (b != (int)blockIdx.x) __syncthreads();
         rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
         PHASE_MARK(0);
-        inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b, inner_out[b]
-        __syncthreads();
+        inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
+        if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1);
-        conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem);  // reads Eo[b] (written above), writes C_0[b]
+        conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem, CL[0]);   // reads Eo[b], writes C_0[b]
         for (int l = 1; l < fa.live; ++l) {
-            __syncthreads();
+            if (lds_act) lds_barrier(); else __syncthreads();
             PHASE_MARK(1 + l);
             const ConvArgs& ca = fa.conv[l];
             const int64_t rows = 1ll << (2 * ca.lgSo), m_lo = (int64_t)b * rows, m_hi = m_lo + rows;
             if (rows >= 64) {
                 for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
-                    if (m0 > m_lo) __syncthreads();
-                    conv_fwd_taps_body<NT, 4 / G, false, G>(ca, m0, m_hi, smem);
+                    if (m0 > m_lo) lds_barrier();
+                    conv_fwd_taps_body<NT, 4 / G, false, G>(ca, m0, m_hi, smem, CL[l - 1], CL[l], m_lo);
                 }
             } else if (rows >= 32) {
-                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G>(ca, m_lo, m_hi, smem);
+                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
             } else {
-                conv_fwd_taps_body<NT, 1, false, G>(ca, m_lo, m_hi, smem);
+                conv_fwd_taps_body<NT, 1, false, G>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
             }
         }
-        __syncthreads();
+        if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1 + fa.live);
-        head_fwd_body<NW>(fa.head, b, smem);
+        head_fwd_body<NW>(fa.head, b, smem, lds_act ? CL : nullptr);
         PHASE_MARK(2 + fa.live);
     }
 }
@@ -2250,6 +2267,23 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
     if (l_fact > lds) lds = l_fact;
     if (l_taps > lds) lds = l_taps;
     if (head_fwd_lds(g) > lds) lds = head_fwd_lds(g);
+    // LDS-resident activations: C_0 above every phase's scratch, C_1.. above the scratch of the tap kernels / the head
+    {
+        const size_t c0 = (size_t)S * S * PP * 4;
+        size_t small = 0;
+        for (int l = 1; l < g.live; ++l) small += (size_t)(g.D >> (l + 1)) * (g.D >> (l + 1)) * PP * 4;
+        size_t low = l_taps > head_fwd_lds(g) ? l_taps : head_fwd_lds(g);       // scratch of the phases that run while C_1.. live
+        low = (low + 255) / 256 * 256;
+        size_t base0 = lds > low + small ? lds : low + small;
+        base0 = (base0 + 255) / 256 * 256;
+        for (int l = 0; l < CFFM_MAX_LAYERS; ++l) fa.c_off[l] = -1;
+        if (base0 + c0 <= 160 * 1024 - 512) {
+            fa.c_off[0] = (int)base0;
+            size_t o = low;
+            for (int l = 1; l < g.live; ++l) { fa.c_off[l] = (int)o; o += (size_t)(g.D >> (l + 1)) * (g.D >> (l + 1)) * PP * 4; }
+            lds = base0 + c0;
+        }
+    }
     int rc = 0;
     DISPATCH_NT4(PP / 16, rc = (launch_fwd_all<NT_>(fa, lds, st)));
     return rc;

@@ -36,8 +36,9 @@ static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFF
 
 // NW wavefronts: the pooling sweeps, the embedding tile and s0 use all of them; the dense(32) partials stay on the
 // first 256 threads (8 parts x 32 units)
+// CL != nullptr (fused forward): LDS copies of this example's conv outputs, read instead of the global ones
 template <int NW = 4>
-__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem) {
+__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem, float* const* CL = nullptr) {
     constexpr int NTH = 64 * NW, RPW = 16 / NW;                    // rows per wave in one pooling sweep
     float* t1s = reinterpret_cast<float*>(smem);                   // [1024]
     float (*hpart)[CFFM_HEAD_UNITS] = reinterpret_cast<float (*)[CFFM_HEAD_UNITS]>(t1s + 1024);   // [8][32]
@@ -112,7 +113,8 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
             const int S = g.D >> (l + 1);
             const int n4 = S * g.Pp / 4;
-            const float4* base = reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);
+            const float4* base = CL ? reinterpret_cast<const float4*>(CL[l])
+                                    : reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);
             // wave w owns rows w, w+4, ...; four rows are swept together so that four loads are in flight per lane
             for (int y0 = wave; y0 < S; y0 += 16) {
                 float s4[RPW];
@@ -136,14 +138,14 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             }
             off += S;
         }
-        __syncthreads();                                             // Et (and the pools) are in LDS
+        lds_barrier();                                             // Et (and the pools) are in LDS
         for (int f = wave; f < g.F; f += NW) {                      // row sums of the embedding tile
             float s = 0.f;
             for (int d = lane; d < g.D; d += 64) s += Et[f * g.D + d];
             s = wave_sum(s);
             if (lane == 0) rs[f] = s;
         }
-        __syncthreads();
+        lds_barrier();
         // s0[h] = sum_{w,p} Eo[i_p][h] * Eo[j_p][w] = sum_i Eo[i][h] * sum_{j>i} rowsum(j)   (:381)
         for (int h = tid; h < g.D; h += NTH) {
             float s = 0.f, R = 0.f;
@@ -153,7 +155,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             }
             t1s[h] = s;
         }
-        __syncthreads();
+        lds_barrier();
         for (int k = tid; k < t1w; k += NTH) a.t1[(int64_t)b * t1w + k] = t1s[k];
         if (tid < 256) {                                             // dense(32), :409: 8 partial sums per unit
             float s = 0.f;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             }
             hpart[part][q] = s;
         }
-        __syncthreads();
+        lds_barrier();
         if (wave == 0) {                                             // + bias, then dense(1) * beta, :410, :414
             float h = 0.f;
             if (lane < CFFM_HEAD_UNITS) {
@@ -182,7 +184,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             if (lane == 0) sc[0] = g.beta_outer * (v + d2b);
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         if (a.outer_conv) o = sc[0];
         float out = io;
