@@ -582,8 +582,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #ifdef CFFM_PHASE_TIMERS
 // debug build only (make PHASE_TIMERS=1): 100 MHz timestamps of workgroup 7's phase boundaries
 __device__ unsigned long long cffm_phase_times[16];
+__device__ unsigned long long cffm_wg_times[2 * 1024];
 #define PHASE_MARK(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[i] = wall_clock64(); } while (0)
 #define PHASE_MARK2(i) do { if (a.lgSo == 3 && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
+extern "C" int cffm_debug_wg_times(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cffm_wg_times), sizeof(cffm_wg_times));
+}
 extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
     return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(cffm_phase_times), sizeof(cffm_phase_times));
 }
@@ -1042,6 +1046,9 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
 #pragma unroll
     for (int l = 0; l < CFFM_MAX_LAYERS; ++l) CL[l] = fa.c_off[l] >= 0 ? reinterpret_cast<float*>(smem + fa.c_off[l]) : nullptr;
     const bool lds_act = fa.c_off[0] >= 0;
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x] = wall_clock64();
+#endif
     for (int b = blockIdx.x; b < fa.B; b += gridDim.x) {
         if (b != (int)blockIdx.x) __syncthreads();
         rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
@@ -1071,6 +1078,9 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
         head_fwd_body<NW>(fa.head, b, smem, lds_act ? CL : nullptr);
         PHASE_MARK(2 + fa.live);
     }
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // conv0_fact_bwd: the whole backward of layer 0 in factorised form (S = 16, small Pp), one workgroup per
