@@ -160,15 +160,26 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
         hipError_t e = hipMemsetAsync(w + wl.gpart, 0, (size_t)wl.gpart_floats * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
-    if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, stream, unscaled))) return rc;
     bool inner_done = false;
-    if (s->outer_conv) {
-        for (int l = g.live - 1; l >= 1; --l) {
-            if (l == g.live - 1) rc = cffm_conv_bwd_with_inner(s, theta, ws, B, l, stream, &inner_done);
-            else rc = cffm_conv_bwd(s, theta, ws, B, l, stream);
-            if (rc) return rc;
-        }
+    if (bwd_top_ok(s, B) && s->loss != CFFM_LOSS_SQUARE_L2) {
+        // head + top two conv layers + inner branch: one launch
+        int next = 0;
+        if ((rc = cffm_bwd_top_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, unscaled, stream, &next)))
+            return rc;
+        inner_done = true;
+        for (int l = next; l >= 1; --l)
+            if ((rc = cffm_conv_bwd(s, theta, ws, B, l, stream))) return rc;
         if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
+    } else {
+        if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, stream, unscaled))) return rc;
+        if (s->outer_conv) {
+            for (int l = g.live - 1; l >= 1; --l) {
+                if (l == g.live - 1) rc = cffm_conv_bwd_with_inner(s, theta, ws, B, l, stream, &inner_done);
+                else rc = cffm_conv_bwd(s, theta, ws, B, l, stream);
+                if (rc) return rc;
+            }
+            if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
+        }
     }
     if (!inner_done && (rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
     if (skip_reduce) return 0;                  // the caller reduces the slabs together with the table update

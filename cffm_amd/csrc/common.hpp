@@ -67,9 +67,20 @@ struct SlabPlan {
     int head_front, inner, conv0, head_back;   // indices into r
 };
 
+// Fused top of the backward (bwd_top_kernel): head + the top two conv layers, one workgroup (= one slab) per example
+static inline bool bwd_top_ok(const cffm_shape_t* s, int32_t B) {
+    const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
+    const int live = ilog2_i(s->D) - 1;
+    return Pp <= 64 && B <= 256 && s->inner_conv && s->outer_conv && live >= 2;
+}
+static inline int bwd_top_first_layer(const cffm_shape_t* s) {
+    const int live = ilog2_i(s->D) - 1;
+    return live - 2 >= 1 ? live - 2 : 1;
+}
 static inline int conv_slabs(const cffm_shape_t* s, int32_t B, int l) {
     const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
     const int64_t S = s->D >> (l + 1);
+    if (bwd_top_ok(s, B) && l >= bwd_top_first_layer(s)) return 256;
     return (Pp <= 64 && (int64_t)B * S * S >= 256 * 64) ? 256 : CFFM_NSLAB;
 }
 
@@ -90,6 +101,22 @@ static inline void make_slab_plan(const cffm_shape_t* s, int32_t B, const cffm_t
     p->head_back = add(tl.d1_w, tl.n, small_slabs(B));
     p->n = n;
     p->total = base;
+}
+
+// dL/dout of one example (CFFM.py:486-513); `out` is what head_fwd left in ws.out (sigmoid(logit) for log_loss)
+__device__ __forceinline__ float head_dout(int loss, float out, float y, float invB, float L) {
+    switch (loss) {
+        case CFFM_LOSS_SQUARE_RMSE: return (out - y) * invB / L;
+        case CFFM_LOSS_MSE: return 2.f * (out - y) * invB;
+        case CFFM_LOSS_MAE: return (out > y ? 1.f : (out < y ? -1.f : 0.f)) * invB;
+        case CFFM_LOSS_SQUARE_L2: return out - y;                 // d/dout of sum (y - out)^2 / 2
+        case CFFM_LOSS_HYBRID:
+            return 0.5f * (out - y) - 0.5f * invB * (y / (out + 1e-7f) - (1.f - y) / (1.f - out + 1e-7f));
+        default: {
+            const float s = out;
+            return -(y / (s + 1e-7f) - (1.f - y) / (1.f - s + 1e-7f)) * invB * s * (1.f - s);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

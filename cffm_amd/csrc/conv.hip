@@ -1376,8 +1376,9 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 // Tj[half][tap][p][x].  A final pass adds, for every (field, h), the Ti / Tj entries of the pairs that contain
 // the field, in pair order: bitwise reproducible, and ~100x cheaper than ds_add_f32 (measured: the atomic
 // version spent 83 K LDS cycles per CU).
+// m_lo / m_end (fused top-of-backward kernel): the tiles start at m_lo and rows >= m_end are masked instead of a.Mtot
 template <int NT, int RM, bool L0, int HALVES>
-__device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem) {
+__device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem, int64_t m_lo = 0, int64_t m_end = -1) {
     constexpr int PP = NT * 16, BM = 16 * RM, NTH = 256 * HALVES, NCOPY = 4 * HALVES;
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]
@@ -1386,7 +1387,8 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
     const int mtiles = rows_per_wg / BM;
-    const int64_t wg_m0 = (int64_t)wg * rows_per_wg;
+    const int64_t Mend = m_end < 0 ? a.Mtot : m_end;
+    const int64_t wg_m0 = m_lo + (int64_t)wg * rows_per_wg;
     const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
     const int exsz = a.F * Dp;
     const bool fast = L0 && RM == 4 && a.lgSo >= 4 && a.lgSo <= 6;      // tiles per y = So/16 divides RM
@@ -1431,7 +1433,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             int64_t m = m0 + rm * 16 + r;
-            if (m >= a.Mtot) m = a.Mtot - 1;
+            if (m >= Mend) m = Mend - 1;
 #pragma unroll
             for (int h = 0; h < NT; ++h) av[rm][h] = *reinterpret_cast<const float4*>(a.dC + m * PP + 16 * h + 4 * kk);
         }
@@ -1445,7 +1447,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int64_t m = m0 + rm * 16 + kk * 4 + j;
-                    if (m >= a.Mtot) m = a.Mtot - 1;
+                    if (m >= Mend) m = Mend - 1;
                     const RowPos rp = row_pos(m, a.lgSo);
                     ppos[rm][j] = (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
                     dpre[rm][j] = a.dt1[(int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y + dh];
@@ -1478,14 +1480,14 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
             const int64_t mrow = m0 + rm * 16 + kk * 4;
-            const RowPos rq = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);
+            const RowPos rq = row_pos(mrow < Mend ? mrow : Mend - 1, a.lgSo);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int p = nt * 16 + r;
                 if (!L0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (mrow + j < a.Mtot) {
+                        if (mrow + j < Mend) {
                             const float g = acc[rm][nt][j] + dpre[L0 ? 0 : rm][j];
                             a.dprev[ppos[L0 ? 0 : rm][j] + nt * 16] = g * act_relu_grad(cpre[L0 ? 0 : rm][L0 ? 0 : nt][j], a.act);
                         }
@@ -1498,7 +1500,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
                         float si = 0.f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = (pv && mrow + j < a.Mtot) ? acc[rm][nt][j] : 0.f;
+                            const float v = (pv && mrow + j < Mend) ? acc[rm][nt][j] : 0.f;
                             si += v * Es[fj * Dp + 2 * (rq.x + j) + dw];
                             accj[rm][nt][j] += v * ei;
                         }
@@ -1513,7 +1515,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int64_t m = mrow + j;
-                            if (pv && m < a.Mtot) {
+                            if (pv && m < Mend) {
                                 const RowPos rp = row_pos(m, a.lgSo);
                                 const int eb = (rp.b - b0) * exsz;
                                 const int io = eb + fi * Dp + 2 * rp.y + dh, jo = eb + fj * Dp + 2 * rp.x + dw;
@@ -1612,7 +1614,8 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 // sub-chunk is cut in two and the two partial blocks of a tap are added (lower half first) through LDS.
 #define WGT_SUB 256
 template <int NT, bool GEN, int HALVES>
-__device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, int nslab, char* smem) {
+__device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, int nslab, char* smem, int64_t m_lo_o = -1,
+                                                int64_t m_hi_o = -1) {
     constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
     float* Bs = reinterpret_cast<float*>(smem);               // [WGT_SUB][PP]
     uint32_t* lut = reinterpret_cast<uint32_t*>(Bs + WGT_SUB * PP);   // GEN: [PP]
@@ -1623,7 +1626,8 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, in
     const int n_ex_max = GEN ? WGT_SUB / S2 + 2 : 0;
     f32x4* red = reinterpret_cast<f32x4*>(Es + (GEN ? (n_ex_max * a.F * Dp + 7) / 4 * 4 : 0));   // HALVES == 2
     const int64_t rows_per_slab = ((a.Mtot + nslab - 1) / nslab + 3) / 4 * 4;
-    const int64_t m_lo = slab * rows_per_slab, m_hi = min(a.Mtot, m_lo + rows_per_slab);
+    const int64_t m_lo = m_lo_o >= 0 ? m_lo_o : slab * rows_per_slab;
+    const int64_t m_hi = m_lo_o >= 0 ? m_hi_o : min(a.Mtot, m_lo + rows_per_slab);
 
     f32x4 acc[NT][NT];
 #pragma unroll
@@ -1776,6 +1780,49 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradAr
     if (bid < n_i) inner_bwd_body(ib, bid, n_i, smem);
     else if (bid < n_i + n_d) dgrad_taps_body<NT, RM, false, 1>(d, bid - n_i, smem);
     else wgrad_taps_body<NT, false, 1>(w, bid - n_i - n_d, n_w, smem);
+}
+
+// Top of the backward in ONE launch (B <= 256, Pp <= 64): workgroup b runs, for example b, the head backward and then
+// the weight- and input-gradient of the top two conv layers (4 and 16 rows per example at D = 32) - five launch
+// boundaries of the per-stage pipeline collapse into barriers of one workgroup.  A second block range carries the
+// inner-branch backward, which recomputes dL/dout from (out, y, L) itself so that it does not wait for the first range.
+struct BwdTopArgs {
+    HeadBwdArgs hb;
+    DgradArgs d[2];
+    WgradArgs w[2];
+    int lgSo[2];
+    int n_layers;                 // 1 or 2 conv layers (top first)
+    InnerBwdArgs ib;
+    int n_inner;                  // workgroups of the inner-branch role (0: none)
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float dh1s[CFFM_HEAD_UNITS];
+    __shared__ float dt1s[1024];
+    __shared__ float red[4];
+    const int bid = blockIdx.x;
+    if (bid < a.n_inner) {                                   // ---- role 1: inner branch
+        const float L = head_bwd_loss(a.hb, false, red);
+        __syncthreads();
+        inner_bwd_body(a.ib, bid, a.n_inner, smem, L);
+        return;
+    }
+    const int b = bid - a.n_inner;                           // ---- role 2: example b (also slab b of every range)
+    HeadBwdState st;
+    head_bwd_begin(a.hb, b, st);
+    const float L = head_bwd_loss(a.hb, b == 0, red);
+    if (b < a.hb.B)
+        head_bwd_example(a.hb, b, st, b, head_dout(a.hb.loss, a.hb.out[b], a.hb.y[b], 1.f / (float)a.hb.Bg, L), dh1s, dt1s);
+    head_bwd_end(a.hb, b, st);
+    for (int t = 0; t < a.n_layers; ++t) {
+        __syncthreads();                                     // dC of this layer (global, written above) is complete
+        const int64_t rows = 1ll << (2 * a.lgSo[t]);
+        const int64_t m_lo = (int64_t)b * rows, m_hi = b < a.hb.B ? m_lo + rows : m_lo;
+        wgrad_taps_body<NT, false, 1>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
+        for (int64_t m0 = m_lo; m0 < m_hi; m0 += 16) dgrad_taps_body<NT, 1, false, 1>(a.d[t], 0, smem, m0, m_hi);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2051,6 +2098,71 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         if (big) { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 2, false>(a, nblk, st))); }
         else { DISPATCH_NT(NT, rc = (launch_conv_fwd<NT_, 1, false>(a, nblk, st))); }
     }
+    return rc;
+}
+
+// argument blocks of the tap-split backward of layer l >= 1
+static void fill_taps_bwd_args(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, DgradArgs* da_, WgradArgs* wa_) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    char* w = (char*)ws;
+    float* gpart = (float*)(w + wl.gpart);
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const SlabRange& sr = sp.r[sp.conv0 + l];
+    int lg;
+    const int64_t Mtot = layer_rows(g, B, l, &lg);
+    WgradArgs& wa = *wa_;
+    wa.in = (const float*)(w + wl.C[l - 1]);
+    wa.dC = (const float*)(w + wl.dC[l]);
+    wa.slabW = gpart + sr.base; wa.slabB = wa.slabW + (tl.conv_b[l] - tl.conv_w[l]);
+    wa.slab_stride = sr.len; wa.slabB_stride = sr.len;
+    wa.Mtot = Mtot; wa.lgSo = lg;
+    wa.B = B; wa.P = g.P; wa.Pp = g.Pp; wa.F = g.F; wa.D = g.D; wa.act = g.act; wa.qblocks = 0;
+    DgradArgs& da = *da_;
+    da.dC = wa.dC;
+    da.W = theta + tl.conv_w[l];
+    da.Cprev = wa.in;
+    da.dt1 = (const float*)(w + wl.dt1);
+    da.dprev = (float*)(w + wl.dC[l - 1]);
+    da.Mtot = Mtot; da.lgSo = lg;
+    da.B = B; da.P = g.P; da.Pp = g.Pp; da.F = g.F; da.D = g.D; da.act = g.act;
+    da.t1w = 2 * g.D - 2; da.t1off = t1_offset(g, l);
+}
+
+template <int NT>
+static int launch_bwd_top(const BwdTopArgs& a, size_t lds, hipStream_t st) {
+    int rc = set_lds(bwd_top_kernel<NT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bwd_top_kernel<NT>), dim3(a.n_inner + 256), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// head backward + the top conv layers (+ the inner-branch backward) in one launch; *next_layer receives the highest
+// conv layer the caller still has to run (layers >= 1 below it, then layer 0)
+int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
+                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer) {
+    const Geo g = make_geo(s);
+    BwdTopArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_head_bwd_args(s, theta, ws, y, B, B_global, local_sum, loss_out, unscaled, &a.hb);
+    const int first = bwd_top_first_layer(s);
+    a.n_layers = 0;
+    for (int l = g.live - 1; l >= first; --l) {
+        fill_taps_bwd_args(s, theta, ws, B, l, &a.d[a.n_layers], &a.w[a.n_layers]);
+        a.lgSo[a.n_layers] = a.d[a.n_layers].lgSo;
+        ++a.n_layers;
+    }
+    a.n_inner = fill_inner_bwd_args(s, theta, ws, B, &a.ib);
+    a.ib.dout = nullptr;                                     // recomputed from (out, y, L): no dependency on the head role
+    a.ib.y = y; a.ib.invB = 1.f / (float)B_global;
+    size_t lds = (size_t)(WGT_SUB * g.Pp) * 4 + 16;
+    if (inner_bwd_lds(g) > lds) lds = inner_bwd_lds(g);
+    int rc = 0;
+    DISPATCH_NT4(g.Pp / 16, rc = (launch_bwd_top<NT_>(a, lds, st)));
+    *next_layer = first - 1;
     return rc;
 }
 

@@ -198,3 +198,196 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     }
 }
 
+struct HeadBwdArgs {
+    Geo g;
+    int B;
+    int64_t Bg;
+    const float *fb, *t1, *h1, *att, *out, *y, *Ctop;
+    const float *d1_w, *d2_w, *att_W, *lin_w;
+    float* scalars;
+    const float* sqerr;      // non-NULL: sum the B local loss terms here instead of reading scalars[3]
+    float* loss_out;         // may be NULL
+    float *dout, *dt1, *dfb, *dCtop;
+    float *s_attW, *s_attb, *s_bias, *s_d1w, *s_d1b, *s_d2w, *s_d2b, *s_linw, *s_linb;   // slab 0 pointers
+    int64_t stride_front, stride_back;    // slab strides of the head-front (att_W, att_b, bias) and head-back ranges
+    int64_t front_len, back_len;
+    int loss, outer_conv;
+    int unscaled;            // 1: leave the 1/L of the RMSE-style loss out of dout (data-parallel late scaling)
+};
+
+// The backward of the head is written as begin / loss / example / end so that the stand-alone kernel (one workgroup per
+// slab looping over its examples) and the fused top-of-backward kernel share it.
+struct HeadBwdState {
+    float g_d2w, g_d1b, g_d2b, g_bias, g_linw, g_linb, g_attb;
+    bool first;
+};
+
+__device__ __forceinline__ void head_bwd_begin(const HeadBwdArgs& a, int slab, HeadBwdState& st) {
+    const int tid = threadIdx.x;
+    float* s_attW = a.s_attW + (int64_t)slab * a.stride_front;
+    float* s_d1w = a.s_d1w + (int64_t)slab * a.stride_back;
+    // zero this slab's two ranges first (alignment gaps and members this configuration never writes)
+    for (int64_t e = tid; e < a.front_len; e += 256) s_attW[e] = 0.f;        // att_W is the first member of the range
+    for (int64_t e = tid; e < a.back_len; e += 256) s_d1w[e] = 0.f;          // d1_w is the first member of the range
+    st.g_d2w = st.g_d1b = st.g_d2b = st.g_bias = st.g_linw = st.g_linb = st.g_attb = 0.f;
+    st.first = true;
+    __syncthreads();
+}
+
+// The loss L (CFFM.py:486-513) from the per-example terms, summed in the same fixed order by every workgroup; workgroup
+// `publisher` also writes it out.  red: LDS [4].
+__device__ __forceinline__ float head_bwd_loss(const HeadBwdArgs& a, bool publisher, float* red) {
+    const int tid = threadIdx.x;
+    float sum = 0.f, hybrid_log = 0.f;
+    if (a.loss == CFFM_LOSS_HYBRID) {      // two sums with different normalisers: taken from out / y directly
+        float p_sq = 0.f, p_log = 0.f;
+        for (int i = tid; i < a.B; i += 256) {
+            const float o = a.out[i], yy = a.y[i];
+            p_sq += 0.5f * (yy - o) * (yy - o);
+            p_log -= yy * logf(o + 1e-7f) + (1.f - yy) * logf(1.f - o + 1e-7f);
+        }
+        sum = block_sum(p_sq, red);
+        __syncthreads();
+        hybrid_log = block_sum(p_log, red);
+        __syncthreads();
+    } else if (a.unscaled) {
+        sum = 0.f;           // not known yet: the caller all-reduces it together with the gradients
+    } else if (a.sqerr) {    // same fixed-order sum in every workgroup
+        float part = 0.f;
+        for (int i = tid; i < a.B; i += 256) part += a.sqerr[i];
+        sum = block_sum(part, red);
+        __syncthreads();
+    } else {
+        sum = a.scalars[3];
+    }
+    const float invB = 1.f / (float)a.Bg;
+    float L;
+    if (a.loss == CFFM_LOSS_SQUARE_RMSE) L = a.unscaled ? 1.f : sqrtf(sum * invB + 1e-10f);   // CFFM.py:493
+    else if (a.loss == CFFM_LOSS_SQUARE_L2) L = sum;            // data term only (the regularisers are not summed here)
+    else if (a.loss == CFFM_LOSS_HYBRID) L = 0.5f * sum + 0.5f * hybrid_log * invB;   // CFFM.py:511-513
+    else L = sum * invB;
+    if (publisher && tid == 0) {
+        a.scalars[1] = L;
+        if (a.sqerr) { a.scalars[0] = sum; a.scalars[3] = sum; }
+        if (a.loss_out) a.loss_out[0] = L;
+    }
+    return L;
+}
+
+// dh1s [CFFM_HEAD_UNITS] and dt1s [2D-2] are LDS scratch of the caller
+__device__ __forceinline__ void head_bwd_example(const HeadBwdArgs& a, int slab, HeadBwdState& st, int b, float d,
+                                                 float* dh1s, float* dt1s) {
+    const Geo& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t1w = 2 * g.D - 2;
+    float* s_attW = a.s_attW + (int64_t)slab * a.stride_front;
+    float* s_d1w = a.s_d1w + (int64_t)slab * a.stride_back;
+    const bool first = st.first;
+    int off_top = 0;
+    for (int i = 0; i < g.live; ++i) off_top += g.D >> i;
+    if (tid == 0) { a.dout[b] = d; st.g_bias += d; }
+    __syncthreads();
+    if (a.outer_conv) {
+        const float dd = d * g.beta_outer;
+        if (tid < CFFM_HEAD_UNITS) {
+            const float v = dd * a.d2_w[tid];
+            dh1s[tid] = v;
+            st.g_d2w += a.h1[(int64_t)b * CFFM_HEAD_UNITS + tid] * dd;
+            st.g_d1b += v;
+        }
+        if (tid == 0) st.g_d2b += dd;
+        __syncthreads();
+        for (int k = tid; k < t1w; k += 256) {
+            float s = 0.f;
+            for (int q = 0; q < CFFM_HEAD_UNITS; ++q) s += dh1s[q] * a.d1_w[k * CFFM_HEAD_UNITS + q];
+            dt1s[k] = s;
+            a.dt1[(int64_t)b * t1w + k] = s;
+        }
+        for (int e = tid; e < t1w * CFFM_HEAD_UNITS; e += 256) {
+            const int k = e / CFFM_HEAD_UNITS, q = e % CFFM_HEAD_UNITS;
+            const float v = a.t1[(int64_t)b * t1w + k] * dh1s[q];
+            s_d1w[e] = first ? v : s_d1w[e] + v;
+        }
+        __syncthreads();
+        // gradient wrt the top live conv output: only its sum pool feeds the head
+        const int ntop = 4 * g.Pp;
+        for (int e = tid; e < ntop; e += 256) {
+            const int yy = e / (2 * g.Pp);
+            const int64_t idx = (int64_t)b * ntop + e;
+            a.dCtop[idx] = dt1s[off_top + yy] * act_relu_grad(a.Ctop[idx], g.act);
+        }
+    }
+    if (wave == 0) {
+        const float fbv = lane < g.F ? a.fb[(int64_t)b * g.F + lane] : 0.f;
+        if (g.linear_att) {
+            const float at = lane < g.F ? a.att[(int64_t)b * g.F + lane] : 0.f;
+            const float dg = lane < g.F ? d * a.lin_w[lane] : 0.f;
+            const float da = dg * fbv;
+            const float sda = wave_sum(da * at);
+            const float dz = at * (da - sda) / g.lamda_att;
+            float dfbv = dg * at;
+            for (int gI = 0; gI < g.F; ++gI) {
+                const float dzg = __shfl(dz, gI, 64);
+                if (lane < g.F) {
+                    dfbv += dzg * a.att_W[lane * g.F + gI];
+                    const float v = fbv * dzg;
+                    s_attW[lane * g.F + gI] = first ? v : s_attW[lane * g.F + gI] + v;
+                }
+            }
+            if (lane < g.F) a.dfb[(int64_t)b * g.F + lane] = dfbv;
+            st.g_linw += fbv * at * d;
+            st.g_attb += dz;
+            if (lane == 0) st.g_linb += d;
+        } else if (lane < g.F) {
+            a.dfb[(int64_t)b * g.F + lane] = d;
+        }
+    }
+    st.first = false;
+}
+
+__device__ __forceinline__ void head_bwd_end(const HeadBwdArgs& a, int slab, const HeadBwdState& st) {
+    const int tid = threadIdx.x;
+    const int64_t sof = (int64_t)slab * a.stride_front, sob = (int64_t)slab * a.stride_back;
+    if (tid < CFFM_HEAD_UNITS) {
+        a.s_d2w[sob + tid] = st.g_d2w;
+        a.s_d1b[sob + tid] = st.g_d1b;
+    }
+    if (tid < a.g.F) {
+        a.s_linw[sob + tid] = st.g_linw;
+        a.s_attb[sof + tid] = st.g_attb;
+    }
+    if (tid == 0) {
+        a.s_d2b[sob] = st.g_d2b;
+        a.s_bias[sof] = st.g_bias;
+        a.s_linb[sob] = st.g_linb;
+    }
+}
+
+static inline void fill_head_bwd_args(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B,
+                                      int64_t B_global, bool local_sum, float* loss_out, bool unscaled, HeadBwdArgs* out) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const SlabRange& rf = sp.r[sp.head_front];
+    const SlabRange& rb = sp.r[sp.head_back];
+    float* gf = (float*)(w + wl.gpart) + rf.base - rf.off;        // slab 0 of theta offset x lives at gf + x
+    float* gb = (float*)(w + wl.gpart) + rb.base - rb.off;
+    HeadBwdArgs& a = *out;
+    a.g = make_geo(s); a.B = B; a.Bg = B_global;
+    a.fb = (const float*)(w + wl.fb); a.t1 = (const float*)(w + wl.t1); a.h1 = (const float*)(w + wl.h1);
+    a.att = (const float*)(w + wl.att); a.out = (const float*)(w + wl.out); a.y = y;
+    const int top = a.g.live - 1;
+    a.Ctop = (const float*)(w + wl.C[top]); a.dCtop = (float*)(w + wl.dC[top]);
+    a.d1_w = theta + tl.d1_w; a.d2_w = theta + tl.d2_w; a.att_W = theta + tl.att_W; a.lin_w = theta + tl.lin_w;
+    a.scalars = (float*)(w + wl.scalars);
+    a.sqerr = local_sum ? (const float*)(w + wl.sqerr) : nullptr;
+    a.loss_out = loss_out;
+    a.dout = (float*)(w + wl.dout); a.dt1 = (float*)(w + wl.dt1); a.dfb = (float*)(w + wl.dfb);
+    a.s_attW = gf + tl.att_W; a.s_attb = gf + tl.att_b; a.s_bias = gf + tl.bias;
+    a.s_d1w = gb + tl.d1_w; a.s_d1b = gb + tl.d1_b; a.s_d2w = gb + tl.d2_w; a.s_d2b = gb + tl.d2_b;
+    a.s_linw = gb + tl.lin_w; a.s_linb = gb + tl.lin_b;
+    a.stride_front = rf.len; a.stride_back = rb.len; a.front_len = rf.len; a.back_len = rb.len;
+    a.loss = s->loss; a.outer_conv = s->outer_conv; a.unscaled = unscaled ? 1 : 0;
+}

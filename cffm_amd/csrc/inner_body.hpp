@@ -105,13 +105,16 @@ struct InnerBwdArgs {
     Geo g;
     int B;
     const float *Ei, *dout, *cw, *cb, *wd;
+    const float *out, *y;                             // dout == NULL: dL/dout = head_dout(loss, out[b], y[b], invB, L) on the fly
+    int loss;
+    float invB;
     float* dEi;
     float *slab_cw, *slab_cb, *slab_dw, *slab_db;     // slab 0
     int64_t slab_stride;
 };
 static inline size_t inner_bwd_lds(const Geo& g) { return (size_t)(5 * g.F * g.K + g.Pp + 8) * 4; }
 
-__device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, int nslab, char* smem) {
+__device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, int nslab, char* smem, float L = 1.f) {
     const Geo& g = a.g;
     const int B = a.B;
     const float* __restrict__ Ei = a.Ei; const float* __restrict__ dout = a.dout;
@@ -141,7 +144,7 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
         for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
         for (int i = threadIdx.x; i < 4 * FK; i += blockDim.x) dE[i] = 0.f;
         __syncthreads();
-        const float db = dout[b];
+        const float db = dout ? dout[b] : head_dout(a.loss, a.out[b], a.y[b], a.invB, L);
         float* myE = dE + wave * FK;
         for (int u = threadIdx.x; u < units; u += blockDim.x) {
             const int p = fast_div(u, invK2), t = u - p * K2;
@@ -200,6 +203,7 @@ static inline int fill_inner_bwd_args(const cffm_shape_t* s, const float* theta,
     InnerBwdArgs& a = *out;
     a.g = make_geo(s); a.B = B;
     a.Ei = (const float*)(w + wl.Ei); a.dout = (const float*)(w + wl.dout);
+    a.out = (const float*)(w + wl.out); a.y = nullptr; a.loss = s->loss; a.invB = 1.f / (float)B;
     a.cw = theta + tl.inner_cw; a.cb = theta + tl.inner_cb; a.wd = theta + tl.inner_dw;
     a.dEi = (float*)(w + wl.dEi);
     a.slab_cw = base + tl.inner_cw; a.slab_cb = base + tl.inner_cb; a.slab_dw = base + tl.inner_dw; a.slab_db = base + tl.inner_db;

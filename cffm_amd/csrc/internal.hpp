@@ -27,6 +27,9 @@ int cffm_conv_bwd_part(const cffm_shape_t* s, const float* theta, void* ws, int3
 // as two roles of one launch; the keys must already be sorted in ws.sort_vals
 int cffm_update_all(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc, float* theta,
                     float* theta_acc, float* grad, void* ws, int32_t B, hipStream_t st);
+// fused top of the backward (bwd_top_ok(s, B)): head + top conv layers + inner branch in one launch
+int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
+                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer);
 // backward of conv layer `layer`; where the paired launch is available it also carries the inner-branch backward
 // (*inner_done = true), which the caller must then not launch again
 int cffm_conv_bwd_with_inner(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st,
