@@ -210,6 +210,10 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }
 
+extern "C" int cffm_dp_runs_ok(const cffm_shape_t* s, int32_t B) {
+    return (check_shape(s) == 0 && B > 0 && cffm_fwd_all_ok(s, B)) ? 1 : 0;
+}
+
 // Local half of a data-parallel step in one call: forward (one launch at the README shapes), backward with
 // dL/dout = (out - y) / B_global, then slab reduction ∥ row packing.  Same outputs as cffm_forward + cffm_backward_unscaled.
 extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
@@ -220,11 +224,12 @@ extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, co
     if (B <= 0) return 0;
     if (!s->inner_conv || !s->outer_conv || !y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)
         return CFFM_ERR_UNSUPPORTED;
-    if (cffm_fwd_all_ok(s, B)) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st);
+    const bool run = cffm_fwd_all_ok(s, B);          // the single-launch forward also leaves this rank's keys sorted
+    if (run) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st);
     else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st);
     if (rc) return rc;
     if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, st, true, true))) return rc;
-    return cffm_dp_tail(s, ids, B, ws, grad, rows, st);
+    return cffm_dp_tail(s, ids, B, ws, grad, rows, run, st);
 }
 
 extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,

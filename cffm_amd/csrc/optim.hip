@@ -105,6 +105,55 @@ __device__ __forceinline__ void rank_place_body(int wg, int nwg, const int32_t* 
     }
 }
 
+// Global order of n_runs sorted runs of m keys each (every rank's own run, made by the single-launch forward) without
+// sorting them again: the place of the key at (run r, position p) is p + sum over the other runs of the number of keys
+// that precede it there - an upper bound on its id in the runs before r, a lower bound in the runs after r (the global
+// slot r*m + local slot breaks id ties in run order).  Every workgroup stages all ids (4*n bytes) in LDS once and its
+// 256 threads run n_runs - 1 binary searches each.
+struct MergeArgs {
+    const float* rows;            // n_runs blocks of [m*W | m keys (u64)]
+    int64_t block_floats;         // m * (W + 2)
+    int64_t keys_off;             // m * W
+    int m, n_runs;
+    unsigned long long* out;      // [n_runs * m] keys (id << 32 | global slot) in global order
+};
+__device__ __forceinline__ void merge_runs_body(int wg, const MergeArgs& a, unsigned* ids_l /* LDS [n] */) {
+    const int n = a.m * a.n_runs;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int r = e / a.m, p = e - r * a.m;
+        const unsigned long long k = reinterpret_cast<const unsigned long long*>(a.rows + (int64_t)r * a.block_floats + a.keys_off)[p];
+        ids_l[e] = (unsigned)(k >> 32);
+    }
+    __syncthreads();
+    const int e = wg * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int r = e / a.m, p = e - r * a.m;
+    const unsigned long long k = reinterpret_cast<const unsigned long long*>(a.rows + (int64_t)r * a.block_floats + a.keys_off)[p];
+    const unsigned id = (unsigned)(k >> 32);
+    int rank = p;
+    for (int q = 0; q < a.n_runs; ++q) {
+        if (q == r) continue;
+        const unsigned* run = ids_l + q * a.m;
+        int lo = 0, hi = a.m;                                  // first position whose id is > id (q < r) or >= id (q > r)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned v = run[mid];
+            const bool before = q < r ? v <= id : v < id;
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    a.out[rank] = ((unsigned long long)id << 32) | (unsigned long long)(unsigned)(r * a.m + (int)(k & 0xffffffffull));
+}
+
+__global__ __launch_bounds__(256) void dp_head_merge_kernel(float* __restrict__ v, float* __restrict__ acc, const float* __restrict__ grad,
+                                                            int64_t n, float lr, LateScale ls, float* __restrict__ loss_out,
+                                                            int n_dense, MergeArgs ma) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < n_dense) dense_adagrad_body(blockIdx.x, v, acc, grad, n, lr, ls, loss_out);
+    else merge_runs_body(blockIdx.x - n_dense, ma, reinterpret_cast<unsigned*>(smem));
+}
+
 // first launch of cffm_dp_apply: dense Adagrad with the late 1/L ∥ placement of the gathered keys
 __global__ __launch_bounds__(256) void dp_head_kernel(float* __restrict__ v, float* __restrict__ acc, const float* __restrict__ grad,
                                                       int64_t n, float lr, LateScale ls, float* __restrict__ loss_out, int n_dense,
@@ -122,6 +171,7 @@ struct PackArgs {
     int K, D, B;
     const float *dEi, *dEo, *dfb, *sqerr;
     float *sum_dst, *rows, *scalars;
+    const unsigned long long* keys_sorted;   // non-NULL: appended after the rows as this rank's sorted run
 };
 __device__ __forceinline__ void pack_rows_body(int bid, int nblk, const PackArgs& a, float* red) {
     const int W = 1 + a.K + a.D + 1;
@@ -142,6 +192,10 @@ __device__ __forceinline__ void pack_rows_body(int bid, int nblk, const PackArgs
         else v = a.dfb[slot];
         a.rows[i] = v;
     }
+    if (a.keys_sorted != nullptr) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.rows + total);      // total * 4 bytes is 8-byte aligned: see cffm_dp_tail
+        for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < a.n_slots; i += (int64_t)nblk * 256) dst[i] = a.keys_sorted[i];
+    }
 }
 __global__ __launch_bounds__(256) void dp_tail_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp, float* __restrict__ grad,
                                                       int n_reduce, PackArgs pa, int n_pack) {
@@ -150,7 +204,8 @@ __global__ __launch_bounds__(256) void dp_tail_kernel(const float* __restrict__ 
     else pack_rows_body(blockIdx.x - n_reduce, n_pack, pa, red);
 }
 
-int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws, float* grad, float* rows, hipStream_t st) {
+int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws, float* grad, float* rows, bool with_run,
+                 hipStream_t st) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
@@ -160,6 +215,8 @@ int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws,
     pa.ids = ids; pa.n_slots = (int64_t)B * s->F; pa.K = s->K; pa.D = s->D; pa.B = B;
     pa.dEi = (const float*)(w + wl.dEi); pa.dEo = (const float*)(w + wl.dEo); pa.dfb = (const float*)(w + wl.dfb);
     pa.sqerr = (const float*)(w + wl.sqerr); pa.sum_dst = grad + tl.n; pa.rows = rows; pa.scalars = (float*)(w + wl.scalars);
+    // n_slots * W floats: W = K + D + 2 is even for the float4-aligned K, D this library accepts, so the run is 8-byte aligned
+    pa.keys_sorted = with_run ? (const unsigned long long*)(w + wl.sort_vals) : nullptr;
     const int n_reduce = (int)((tl.n + 255) / 256);
     const int64_t total = pa.n_slots * (1 + s->K + s->D + 1);
     int n_pack = (int)((total + 1023) / 1024);
@@ -194,6 +251,9 @@ struct SparseArgs {
     float lr;
     int64_t sEi, sEo, sfb;
     LateScale ls;
+    int run_len;            // > 0: slot s lives in block s / run_len at local index s % run_len; blocks are run_stride floats apart
+    int64_t run_stride;
+    float inv_run_len;
 };
 
 __device__ __forceinline__ void sparse_adagrad_body(int bid, const SparseArgs& a) {
@@ -217,8 +277,14 @@ __device__ __forceinline__ void sparse_adagrad_body(int bid, const SparseArgs& a
             for (int64_t q = pos; q < n; ++q) {
                 const unsigned long long kq = keys[q];
                 if ((int)(kq >> 32) != id) break;
-                const int64_t sl = (int64_t)(kq & 0xffffffffull);
-                g += c < Ki ? dEi[sl * a.sEi + c] : (c < W - 1 ? dEo[sl * a.sEo + (c - Ki)] : dfb[sl * a.sfb]);
+                int64_t sl = (int64_t)(kq & 0xffffffffull);
+                int64_t boff = 0;
+                if (a.run_len > 0) {
+                    const int blk = fast_div((int)sl, a.inv_run_len);
+                    boff = (int64_t)blk * a.run_stride;
+                    sl -= (int64_t)blk * a.run_len;
+                }
+                g += c < Ki ? dEi[boff + sl * a.sEi + c] : (c < W - 1 ? dEo[boff + sl * a.sEo + (c - Ki)] : dfb[boff + sl * a.sfb]);
             }
             g *= gscale;
             float *vp, *ap;
@@ -333,6 +399,7 @@ static void fill_sparse_args(const cffm_shape_t* s, const cffm_tables_t* tab, co
     a.inner = tab->inner_emb; a.outer = tab->outer_emb; a.fbias = tab->feat_bias;
     a.a_inner = acc->inner_emb; a.a_outer = acc->outer_emb; a.a_fbias = acc->feat_bias;
     a.lr = s->lr; a.sEi = sEi; a.sEo = sEo; a.sfb = sfb; a.ls = ls;
+    a.run_len = 0; a.run_stride = 0; a.inv_run_len = 0.f;
 }
 
 int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, int64_t n_rows,
@@ -378,7 +445,7 @@ int cffm_update_all(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_
 // theta.n], rows = all-gathered packed rows [n_rows][1 + K + D + 1] = (id bits | dEi | dEo | dfb).
 extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, float* theta,
                              float* theta_acc, const float* grad_sum, int64_t B_global, const float* rows,
-                             int64_t n_rows, void* ws, int32_t B_ws, float* loss_out, void* stream) {
+                             int64_t n_rows, void* ws, int32_t B_ws, float* loss_out, int32_t n_runs, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
@@ -388,6 +455,31 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
     LateScale ls = {grad_sum + tl.n, 1.f / (float)B_global, s->loss == CFFM_LOSS_SQUARE_RMSE ? 1 : 0};
     const int64_t W = 1 + s->K + s->D + 1;
     const int n_dense = (int)((tl.n + 255) / 256);
+    if (n_runs > 0) {
+        // sorted runs (one per rank, from cffm_dp_local): merge by rank, rows addressed block-wise
+        if (n_rows <= 0 || n_rows % n_runs || n_rows > (int64_t)B_ws * s->F || n_rows * 4 > 150 * 1024) return CFFM_ERR_BAD_SHAPE;
+        const int m = (int)(n_rows / n_runs);
+        if (m % s->F || !cffm_fwd_all_ok(s, m / s->F)) return CFFM_ERR_UNSUPPORTED;      // the runs only exist on that path
+        cffm_ws_layout_t wl;
+        cffm_ws_layout(s, B_ws, &wl);
+        MergeArgs ma;
+        ma.rows = rows; ma.block_floats = (int64_t)m * (W + 2); ma.keys_off = (int64_t)m * W; ma.m = m; ma.n_runs = n_runs;
+        ma.out = (unsigned long long*)((char*)ws + wl.sort_vals);
+        const size_t lds = (size_t)n_rows * 4;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)dp_head_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(dp_head_merge_kernel, dim3(n_dense + (unsigned)((n_rows + 255) / 256)), dim3(256), lds, st, theta, theta_acc,
+                           grad_sum, (int64_t)tl.n, s->lr, ls, loss_out, n_dense, ma);
+        CFFM_CHECK_LAUNCH();
+        SparseArgs a;
+        fill_sparse_args(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws, B_ws, ls, &a);
+        a.run_len = m; a.run_stride = ma.block_floats; a.inv_run_len = 1.f / (float)m;
+        hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, a);
+        CFFM_CHECK_LAUNCH();
+        return 0;
+    }
     if (n_rows > 0 && n_rows <= 8192 && n_rows <= (int64_t)B_ws * s->F) {
         // dense update and key placement are independent: one launch, two roles
         cffm_ws_layout_t wl;

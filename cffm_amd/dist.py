@@ -62,7 +62,7 @@ class DataParallelStep(object):
             self._gathered[rows.shape] = out
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_gather_into_tensor(out, rows, group=self.group)
-        return c.dp_apply(grad, out, Bg)
+        return c.dp_apply(grad, out, Bg, self.world) if hasattr(c, 'dp_local') else c.dp_apply(grad, out, Bg)
 
     def train_step(self, ids, y):
         """ids int32 [B,F], y fp32 [B]: this rank's shard of the global batch (same B on every rank).

@@ -294,27 +294,39 @@ class HipEngine(object):
         return self._grad_full, rows
 
     def dp_local(self, ids, y, B, B_global):
-        """forward + backward_unscaled in one library call (the local half of a data-parallel step)."""
+        """forward + backward_unscaled in one library call (the local half of a data-parallel step).  Returns
+        (grad_full, block): block is ONE flat buffer [B*F*(1+K+D+1) packed rows | B*F sorted 64-bit keys], the unit
+        DataParallelStep all-gathers; cffm_dp_apply merges the per-rank sorted runs instead of sorting again."""
         ids = self._ids(ids)
         buf, _ = self.workspace(B)
         W = 1 + self.cfg.K + self.cfg.D + 1
-        key = ('rows', B)
-        rows = self._ws.get(key)
-        if rows is None:
-            rows = torch.empty((B * self.cfg.F, W), dtype=torch.float32, device=self.device)
-            self._ws[key] = rows
+        key = ('block', B)
+        block = self._ws.get(key)
+        if block is None:
+            block = torch.empty(B * self.cfg.F * (W + 2), dtype=torch.float32, device=self.device)
+            self._ws[key] = block
         hip.check(self.lib.cffm_dp_local(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
-                                         int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(rows), self._stream()))
-        return self._grad_full, rows
+                                         int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(block), self._stream()))
+        return self._grad_full, block
 
-    def dp_apply(self, grad_full, rows_all, B_global):
-        n_rows = rows_all.shape[0]
+    def dp_apply(self, grad_full, rows_all, B_global, n_runs=0):
+        """n_runs = 0: rows_all [n_rows, 1+K+D+1] in any order (cffm_backward_unscaled rows).  n_runs > 0: the flat
+        concatenation of n_runs dp_local blocks."""
+        W = 1 + self.cfg.K + self.cfg.D + 1
+        runs_ok = n_runs > 0 and rows_all.dim() == 1 and bool(self.lib.cffm_dp_runs_ok(
+            C.byref(self.shape), int(rows_all.numel() // (W + 2) // n_runs // self.cfg.F)))
+        if n_runs > 0 and not runs_ok:
+            # the blocks carry no sorted runs (shape outside the single-launch forward): strip the key areas
+            m = rows_all.numel() // (W + 2) // n_runs
+            rows_all = rows_all.reshape(n_runs, m * (W + 2))[:, :m * W].reshape(n_runs * m, W).contiguous()
+            n_runs = 0
+        n_rows = rows_all.numel() // (W + 2) if n_runs > 0 else rows_all.shape[0]
         B_ws = -(-n_rows // self.cfg.F)
         buf, _ = self.workspace(B_ws)
         hip.check(self.lib.cffm_dp_apply(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
                                          _ptr(self.theta), _ptr(self.theta_acc), _ptr(grad_full), int(B_global),
                                          _ptr(rows_all), int(n_rows), _ptr(buf), int(B_ws), _ptr(self.loss_buf),
-                                         self._stream()))
+                                         int(n_runs), self._stream()))
         return self.loss_buf
 
     def apply_dense(self):

@@ -71,7 +71,8 @@ PROTOTYPES = {
     'cffm_forward': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, _P, _P]),
     'cffm_backward': (C.c_int, [_SH, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_backward_unscaled': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
-    'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, _P]),
+    'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, C.c_int32, _P]),
+    'cffm_dp_runs_ok': (C.c_int, [_SH, C.c_int32]),
     'cffm_dp_local': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), _P]),
@@ -97,7 +98,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.cffm_abi_version() != 3:
+    if lib.cffm_abi_version() != 4:
         raise RuntimeError('cffm_amd: ABI version mismatch')
     _lib = lib
     return lib
@@ -131,3 +132,4 @@ def ws_layout(shape, B):
     wl = WsLayout()
     check(load().cffm_ws_layout(C.byref(shape), int(B), C.byref(wl)))
     return wl
+

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 3
+#define CFFM_ABI_VERSION 4
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -170,19 +170,26 @@ int cffm_forward(const cffm_shape_t *s, const cffm_tables_t *tab, const float *t
 int cffm_backward(const cffm_shape_t *s, const float *theta, const float *y, int32_t B, int64_t B_global,
                   void *ws, float *grad, void *stream);
 /* cffm_forward + cffm_backward_unscaled in one call (what one rank runs before the two collectives of a
- * data-parallel step); uses the single-launch forward where the shape allows */
+ * data-parallel step); uses the single-launch forward where the shape allows.  rows must hold B*F*(1+K+D+1 + 2) floats:
+ * the packed rows [B*F][1+K+D+1] followed by this rank's B*F update keys (id << 32 | slot, 64-bit) in sorted order
+ * (a "run"; valid when the single-launch forward ran, i.e. Pp <= 64 and B*F <= 4096) */
+/* 1 if cffm_dp_local with this per-rank batch leaves a valid sorted run behind its rows (else pass n_runs = 0 rows) */
+int cffm_dp_runs_ok(const cffm_shape_t *s, int32_t B);
 int cffm_dp_local(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids, const float *y,
                   int32_t B, int64_t B_global, void *ws, float *grad, float *rows, void *stream);
 /* Data-parallel halves (cffm_amd/dist.py).  cffm_backward_unscaled = cffm_backward with dL/dout = (out - y) / B_global,
  * i.e. without the 1/L of the RMSE-style loss (CFFM.py:493), which needs the loss-term sum over the GLOBAL batch:
  * grad must hold theta.n + 4 floats, grad[theta.n] receives this rank's loss-term sum so that one all-reduce carries
- * gradients and sum; rows [B*F][1+K+D+1] receives (id bits | dEi | dEo | dfb) for one all-gather.  cffm_dp_apply takes
+ * gradients and sum; rows [B*F][1+K+D+1] receives (id bits | dEi | dEo | dfb) for one all-gather.  cffm_dp_apply with
+ * n_runs = 0 takes rows [n_rows][1+K+D+1] in any order and sorts the keys itself; with n_runs > 0 rows is the
+ * concatenation of n_runs cffm_dp_local buffers (n_rows / n_runs slots each): the sorted runs are merged by rank
+ * (binary searches in LDS) instead of a radix sort of all n_rows keys.  cffm_dp_apply takes
  * the all-reduced grad and the all-gathered rows, applies 1/L and the dense + sparse Adagrad updates. */
 int cffm_backward_unscaled(const cffm_shape_t *s, const float *theta, const int32_t *ids, const float *y, int32_t B,
                            int64_t B_global, void *ws, float *grad, float *rows, void *stream);
 int cffm_dp_apply(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *acc, float *theta,
                   float *theta_acc, const float *grad_sum, int64_t B_global, const float *rows, int64_t n_rows,
-                  void *ws, int32_t B_ws, float *loss_out, void *stream);
+                  void *ws, int32_t B_ws, float *loss_out, int32_t n_runs, void *stream);
 /* sess.run((self.loss, self.optimizer)) CFFM.py:200: one fused forward + backward + Adagrad update of
  * theta/tables (and their accumulators) in place; loss (device scalar, may be NULL) receives the loss. */
 int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,

@@ -323,11 +323,14 @@ def test_full_size_configs(name):
     assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
 
 
-def test_data_parallel_halves_on_one_gpu():
-    """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run
-    cffm_backward_unscaled on the two halves of a batch, the test plays the role of the two collectives (sum of the
-    flat gradient buffers, concatenation of the packed rows), and cffm_dp_apply on each replica must reproduce one
-    oracle step on the whole batch - including duplicates of an id that sit on different ranks."""
+@pytest.mark.parametrize('route', ['runs', 'rows'])
+def test_data_parallel_halves_on_one_gpu(route):
+    """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run the local half
+    of the step on the two halves of a batch, the test plays the role of the two collectives (sum of the flat gradient
+    buffers, concatenation of what would be all-gathered), and cffm_dp_apply on each replica must reproduce one oracle
+    step on the whole batch - including duplicates of an id that sit on different ranks.
+    route 'runs': cffm_dp_local blocks (rows + each rank's sorted key run, merged by rank in cffm_dp_apply);
+    route 'rows': cffm_forward + cffm_backward_unscaled rows in any order (sorted inside cffm_dp_apply)."""
     cfg, p32, X, y = make_case('bookx-relu')
     B = X.shape[0]
     h = B // 2
@@ -335,10 +338,10 @@ def test_data_parallel_halves_on_one_gpu():
     ids = [torch.from_numpy(X[:h]).cuda(), torch.from_numpy(X[h:]).cuda()]
     ys = [torch.from_numpy(y[:h]).cuda(), torch.from_numpy(y[h:]).cuda()]
     grads, rows = [], []
-    for k, (e, i, t) in enumerate(zip(engines, ids, ys)):
-        if k == 0:                       # the two routes to the same operands: one library call ...
+    for e, i, t in zip(engines, ids, ys):
+        if route == 'runs':
             g, r = e.dp_local(i, t, h, B)
-        else:                            # ... or the two halves (what ShardedStep uses around its own lookup)
+        else:
             e.forward(i, t)
             g, r = e.backward_unscaled(i, t, h, B)
         grads.append(g.clone()); rows.append(r.clone())
@@ -346,13 +349,12 @@ def test_data_parallel_halves_on_one_gpu():
     gsum = grads[0] + grads[1]                       # all-reduce
     rall = torch.cat(rows, dim=0).contiguous()       # all-gather
     p64 = to64(p32)
-    hook = None
     grads_ref = oracle_dense_grads(p64, X, y, cfg)
     acc = orc.init_accumulators(p64)
     L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
     outs = []
     for e in engines:
-        loss = e.dp_apply(gsum.clone(), rall, B)
+        loss = e.dp_apply(gsum.clone(), rall, B, 2 if route == 'runs' else 0)
         torch.cuda.synchronize()
         close(loss.cpu().numpy(), [L], 'loss')
         outs.append(e.export_params())
@@ -365,6 +367,39 @@ def test_data_parallel_halves_on_one_gpu():
             u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)
             extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
+    touched = np.zeros(cfg.M, dtype=bool)
+    touched[X.reshape(-1)] = True
+    for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+        np.testing.assert_array_equal(outs[0][k][~touched], p32[k][~touched])
+
+
+def test_merge_of_sorted_runs_equals_a_global_sort():
+    """Eight ranks' worth of runs (the N = 8 case the driver measures): the merged key order cffm_dp_apply builds from the
+    per-rank sorted runs is exactly the sorted order of all (id, global slot) keys - checked through its effect: the
+    table update equals the one computed from the same rows handed over unsorted (n_runs = 0, radix sort inside)."""
+    cfg, p32, X, y = make_case('frappe-selu')
+    R, B = 8, 64
+    rng = np.random.default_rng(3)
+    engines = [engine_for(cfg, p32), engine_for(cfg, p32)]
+    W = 1 + cfg.K + cfg.D + 1
+    blocks, rows_only = [], []
+    e0 = engines[0]
+    for r in range(R):
+        Xi = rng.integers(0, 40, size=(B, cfg.F)).astype(np.int32)       # few distinct ids: long segments across ranks
+        yi = rng.choice([-1.0, 1.0], size=(B,)).astype(np.float32)
+        g, blk = e0.dp_local(torch.from_numpy(Xi).cuda(), torch.from_numpy(yi).cuda(), B, R * B)
+        blocks.append(blk.clone())
+        rows_only.append(blk[:B * cfg.F * W].reshape(B * cfg.F, W).clone())
+    grad = g.clone()
+    e1 = engines[1]
+    e0.load_params(p32); e1.load_params(p32)
+    e0.dp_apply(grad.clone(), torch.cat(blocks).contiguous(), R * B, R)
+    e1.dp_apply(grad.clone(), torch.cat(rows_only, dim=0).contiguous(), R * B, 0)
+    torch.cuda.synchronize()
+    a, b = e0.export_params(), e1.export_params()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert not np.array_equal(a['outer_embeddings'], p32['outer_embeddings'])
 
 
 def test_regularised_square_loss_step():
