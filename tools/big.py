@@ -1,6 +1,6 @@
 """Functional + timing check of the big BASELINE configs on one GPU (not part of the test suite)."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cffm_amd import synth
 from cffm_amd.engine import HipEngine
 from cffm_amd.spec import CFFMConfig, init_params

@@ -1,6 +1,6 @@
 """Time cffm_dp_apply alone for the gathered-row counts of N = 1, 2, 4, 8 ranks at the frappe shape (B = 256 per rank)."""
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from bench import workload_cfg, event_time_ms
 from cffm_amd.engine import HipEngine

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <counters...>   (run on the GPU box from the repo root)
+# usage: tools/pmc.sh <outdir> <counters...>   (run on the GPU box from the repo root)
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1

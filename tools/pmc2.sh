@@ -1,0 +1,7 @@
+#!/bin/bash
+# usage: tools/pmc2.sh <outdir> <script args...> -- <counters...>
+out=$1; shift
+args=()
+while [ "$1" != "--" ]; do args+=("$1"); shift; done; shift
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/tools/stage.py "${args[@]}" > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1

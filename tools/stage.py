@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from cffm_amd import synth
 from cffm_amd.engine import HipEngine

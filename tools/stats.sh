@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_stats.sh <outdir> [bench args]   (run on the GPU box from the repo root)
+# usage: tools/stats.sh <outdir> [bench args]   (run on the GPU box from the repo root)
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1

@@ -1,6 +1,6 @@
 """Debug (make PHASE_TIMERS=1): start / end of every workgroup of fwd_all_kernel, 100 MHz clock."""
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from bench import workload_cfg
 from cffm_amd import synth
