@@ -148,7 +148,7 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
 // backward through the slab reduction; fused = single-GPU step (local loss sum, Adagrad folded into the reduction)
 static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
                          int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream,
-                         bool unscaled = false, bool skip_reduce = false) {
+                         bool unscaled = false, bool skip_reduce = false, const int32_t* rank_ids = nullptr) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -164,7 +164,8 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
     if (bwd_top_ok(s, B) && s->loss != CFFM_LOSS_SQUARE_L2) {
         // head + top two conv layers + inner branch: one launch
         int next = 0;
-        if ((rc = cffm_bwd_top_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, unscaled, stream, &next)))
+        if ((rc = cffm_bwd_top_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, unscaled, stream, &next,
+                                    rank_ids)))
             return rc;
         inner_done = true;
         for (int l = next; l >= 1; --l)
@@ -210,6 +211,11 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }
 
+// the key placement can leave the forward launch when the fused top of the backward runs (and is not the L2 loss path)
+static bool defer_rank(const cffm_shape_t* s, int32_t B) {
+    return bwd_top_ok(s, B) && s->loss != CFFM_LOSS_SQUARE_L2 && cffm_fwd_all_ok(s, B);
+}
+
 extern "C" int cffm_dp_runs_ok(const cffm_shape_t* s, int32_t B) {
     return (check_shape(s) == 0 && B > 0 && cffm_fwd_all_ok(s, B)) ? 1 : 0;
 }
@@ -225,10 +231,12 @@ extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, co
     if (!s->inner_conv || !s->outer_conv || !y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)
         return CFFM_ERR_UNSUPPORTED;
     const bool run = cffm_fwd_all_ok(s, B);          // the single-launch forward also leaves this rank's keys sorted
-    if (run) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st);
+    const bool later = run && defer_rank(s, B);
+    if (run) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later);
     else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st);
     if (rc) return rc;
-    if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, st, true, true))) return rc;
+    if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, st, true, true,
+                            later ? ids : nullptr))) return rc;
     return cffm_dp_tail(s, ids, B, ws, grad, rows, run, st);
 }
 
@@ -249,8 +257,10 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
         return cffm_tables_adagrad_l2(s, tab, tab_acc, ids, (int64_t)B * s->F, ws, B, st);
     }
     if (cffm_fwd_all_ok(s, B)) {                 // small-channel shapes: the whole forward (and the key sort) in one launch
-        if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st))) return rc;
-        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st, false, true))) return rc;
+        const bool later = defer_rank(s, B);
+        if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later))) return rc;
+        if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st, false, true, later ? ids : nullptr)))
+            return rc;
         return cffm_update_all(s, tab, tab_acc, theta, theta_acc, grad, ws, B, st);
     }
     rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);

@@ -990,6 +990,7 @@ struct FwdAllArgs {
     const int32_t* ids;
     unsigned long long* keys_sorted;
     int live, n_rows, id_bits, B;
+    int rank_keys;                // 0: the keys are placed later, by the inner-branch role of bwd_top_kernel
     int c_off[CFFM_MAX_LAYERS];   // byte offsets of the LDS copies of C_l inside the dynamic LDS, -1: activations go through global
 };
 
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
 #endif
     for (int b = blockIdx.x; b < fa.B; b += gridDim.x) {
         if (b != (int)blockIdx.x) __syncthreads();
-        rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
+        if (fa.rank_keys) rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
         PHASE_MARK(0);
         inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
         if (lds_act) lds_barrier(); else __syncthreads();
@@ -1794,6 +1795,9 @@ struct BwdTopArgs {
     int n_layers;                 // 1 or 2 conv layers (top first)
     InnerBwdArgs ib;
     int n_inner;                  // workgroups of the inner-branch role (0: none)
+    const int32_t* rank_ids;      // non-NULL: the inner-branch role also places the sparse-update keys of its examples
+    unsigned long long* keys_sorted;   // (moved here from the forward launch, where it sat on the critical path)
+    int n_rows;
 };
 
 template <int NT>
@@ -1806,6 +1810,9 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
     if (bid < a.n_inner) {                                   // ---- role 1: inner branch
         const float L = head_bwd_loss(a.hb, false, red);
         __syncthreads();
+        if (a.rank_ids != nullptr) {
+            for (int b = bid; b < a.hb.B; b += a.n_inner) rank_keys_body<4>(a.rank_ids, a.n_rows, b, a.hb.g.F, a.keys_sorted, smem);
+        }
         inner_bwd_body(a.ib, bid, a.n_inner, smem, L);
         return;
     }
@@ -2143,7 +2150,7 @@ static int launch_bwd_top(const BwdTopArgs& a, size_t lds, hipStream_t st) {
 // head backward + the top conv layers (+ the inner-branch backward) in one launch; *next_layer receives the highest
 // conv layer the caller still has to run (layers >= 1 below it, then layer 0)
 int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
-                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer) {
+                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer, const int32_t* rank_ids) {
     const Geo g = make_geo(s);
     BwdTopArgs a;
     memset(&a, 0, sizeof(a));
@@ -2158,6 +2165,12 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
     a.n_inner = fill_inner_bwd_args(s, theta, ws, B, &a.ib);
     a.ib.dout = nullptr;                                     // recomputed from (out, y, L): no dependency on the head role
     a.ib.y = y; a.ib.invB = 1.f / (float)B_global;
+    if (rank_ids != nullptr && s->F <= RANK_MAXF && (int64_t)B * s->F <= 4096) {
+        cffm_ws_layout_t wl;
+        cffm_ws_layout(s, B, &wl);
+        a.rank_ids = rank_ids; a.n_rows = B * s->F;
+        a.keys_sorted = (unsigned long long*)((char*)ws + wl.sort_vals);
+    }
     size_t lds = (size_t)(WGT_SUB * g.Pp) * 4 + 16;
     if (inner_bwd_lds(g) > lds) lds = inner_bwd_lds(g);
     int rc = 0;
@@ -2338,7 +2351,7 @@ static int launch_fwd_all(const FwdAllArgs& fa, size_t lds, hipStream_t st) {
 }
 
 int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
-                      const float* y, int32_t B, void* ws, hipStream_t st) {
+                      const float* y, int32_t B, void* ws, hipStream_t st, bool rank_keys) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -2376,6 +2389,7 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
     // sort workgroup
     fa.ids = ids; fa.keys_sorted = (unsigned long long*)(w + wl.sort_vals);
     fa.live = g.live; fa.n_rows = B * s->F; fa.B = B;
+    fa.rank_keys = rank_keys ? 1 : 0;
     int bits = 1;
     while ((1ll << bits) < (long long)s->M && bits < 31) ++bits;
     fa.id_bits = bits;

@@ -29,7 +29,8 @@ int cffm_update_all(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_
                     float* theta_acc, float* grad, void* ws, int32_t B, hipStream_t st);
 // fused top of the backward (bwd_top_ok(s, B)): head + top conv layers + inner branch in one launch
 int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, int64_t B_global,
-                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer);
+                      bool local_sum, float* loss_out, bool unscaled, hipStream_t st, int* next_layer,
+                      const int32_t* rank_ids = nullptr);
 // backward of conv layer `layer`; where the paired launch is available it also carries the inner-branch backward
 // (*inner_done = true), which the caller must then not launch again
 int cffm_conv_bwd_with_inner(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st,
@@ -53,7 +54,7 @@ int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const f
 // whole forward of the fused step in one launch (+ the key sort); only for shapes cffm_fwd_all_ok() accepts
 bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B);
 int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
-                      const float* y, int32_t B, void* ws, hipStream_t st);
+                      const float* y, int32_t B, void* ws, hipStream_t st, bool rank_keys = true);
 // CFFM_LOSS_SQUARE_L2: tables updated densely with g = scatter(row grads) + lamda * w (feature_bias stays sparse)
 int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, const int32_t* ids,
                            int64_t n_rows, void* ws, int32_t B_ws, hipStream_t st);
