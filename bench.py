@@ -206,12 +206,21 @@ def cpu_baseline(cfg, X, y, budget_s=9.0):
         m += 1
     dt2 = time.perf_counter() - t0
     torch_rate = m * X.shape[1] / dt2
+    cpu_model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    cpu_model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     best_torch = torch_rate >= numpy_rate
     return {'value': round(max(torch_rate, numpy_rate), 1), 'unit': 'examples/s',
             'cores': int(tthreads if best_torch else threads), 'kind': 'port',
             'sample': 'fp32 train steps on the same batches: torch-CPU twin %d steps in %.1f s = %.0f ex/s (%d threads); '
                       'numpy oracle %d steps in %.1f s = %.0f ex/s (%d BLAS threads); host has %d cores; value = the '
-                      'faster' % (m, dt2, torch_rate, tthreads, n, dt, numpy_rate, threads, os.cpu_count() or 0),
+                      'faster; CPU: %s' % (m, dt2, torch_rate, tthreads, n, dt, numpy_rate, threads, os.cpu_count() or 0, cpu_model),
             'torch_cpu': round(torch_rate, 1), 'numpy_oracle': round(numpy_rate, 1)}
 
 

@@ -150,23 +150,26 @@ def _dp_worker(rank, world):
     cfg, p, X, y = _case()
     comp = OracleCompute(cfg, p)
     step = DataParallelStep(comp)
-    sl = slice(rank * 4, rank * 4 + 4)
+    per = X.shape[0] // world
+    sl = slice(rank * per, rank * per + per)
     loss = step.train_step(torch.from_numpy(X[sl]), torch.from_numpy(y[sl]))
     return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}
 
 
-def test_data_parallel_step_equals_single_process_step():
-    res = _run(_dp_worker, 2)
+@pytest.mark.parametrize('world', [2, 4])
+def test_data_parallel_step_equals_single_process_step(world):
+    res = _run(_dp_worker, world)
     cfg, p, X, y = _case()
     acc = orc.init_accumulators(p)
     L, _ = orc.train_step(p, acc, X, y, cfg)
-    for rank in (0, 1):
+    for rank in range(world):
         loss, got = res[rank]
         assert abs(loss - L) < 1e-12
         for k, v in got.items():
             np.testing.assert_allclose(v, p[k], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
     for k in res[0][1]:                           # replicas stay bit-identical
-        np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+        for rank in range(1, world):
+            np.testing.assert_array_equal(res[0][1][k], res[rank][1][k])
 
 
 def _sharded_step_worker(rank, world):
@@ -178,25 +181,27 @@ def _sharded_step_worker(rank, world):
     comp = ShardedOracleCompute(lcfg, shard_params(p, rank, world))
     assert comp.p['inner_embeddings'].shape[0] == lcfg.M
     step = ShardedStep(comp)
-    sl = slice(rank * 4, rank * 4 + 4)
+    per = X.shape[0] // world
+    sl = slice(rank * per, rank * per + per)
     loss = step.train_step(torch.from_numpy(X[sl]), torch.from_numpy(y[sl]))
     return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}, {k: np.asarray(v) for k, v in comp.acc.items()}
 
 
-def test_row_sharded_step_equals_single_process_step():
-    """cfg5's mode: tables row-sharded r -> rank r % 2, batch split in halves; afterwards the union of the shards and
+@pytest.mark.parametrize('world', [2, 4])
+def test_row_sharded_step_equals_single_process_step(world):
+    """cfg5's mode: tables row-sharded r -> rank r % G, batch split in G parts; afterwards the union of the shards and
     every replicated parameter equal ONE oracle step on the whole batch with whole tables."""
-    res = _run(_sharded_step_worker, 2)
+    res = _run(_sharded_step_worker, world)
     cfg, p, X, y = _case()
     acc = orc.init_accumulators(p)
     L, _ = orc.train_step(p, acc, X, y, cfg)
-    for rank in (0, 1):
+    for rank in range(world):
         loss, got, gacc = res[rank]
         assert abs(loss - L) < 1e-12
         for k, v in got.items():
             if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
-                np.testing.assert_allclose(v, p[k][rank::2], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
-                np.testing.assert_allclose(gacc[k], acc[k][rank::2], rtol=1e-10, atol=1e-14)
+                np.testing.assert_allclose(v, p[k][rank::world], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
+                np.testing.assert_allclose(gacc[k], acc[k][rank::world], rtol=1e-10, atol=1e-14)
             else:
                 np.testing.assert_allclose(v, p[k], rtol=1e-10, atol=1e-12, err_msg='rank %d %s' % (rank, k))
 
