@@ -239,6 +239,9 @@ def main():
                     help='run the data-parallel step (2 collectives) even at world size 1: what one rank of an N-GPU job executes')
     ap.add_argument('--graph', action='store_true',
                     help='data-parallel step as a HIP-graph replay (RCCL collectives captured); eager by default')
+    ap.add_argument('--dp-mode', default='auto', choices=['auto', 'dense', 'gather'],
+                    help='data-parallel exchange: dense image of the table gradients in one all-reduce (small vocabularies) or '
+                         'all-gather of the row gradients; auto picks by size')
     ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
@@ -278,7 +281,7 @@ def main():
     elif world > 1 or args.force_dp:
         from cffm_amd.dist import DataParallelStep
         eng = HipEngine(cfg, seed=2021, device=str(device))
-        dp = DataParallelStep(eng, use_graph=args.graph)
+        dp = DataParallelStep(eng, use_graph=args.graph, mode=args.dp_mode)
         step = lambda i: dp.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: dist.barrier()
     else:

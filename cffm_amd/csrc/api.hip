@@ -240,6 +240,27 @@ extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, co
     return cffm_dp_tail(s, ids, B, ws, grad, rows, run, st);
 }
 
+// Same local half for the dense-table exchange (small vocabularies): flat = [theta gradients | loss sum | table gradient
+// image], cffm_dp_dense_floats(s) floats, to be summed over the ranks by ONE all-reduce and handed to cffm_dp_apply_dense.
+extern "C" int cffm_dp_local_dense(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
+                                   const float* y, int32_t B, int64_t B_global, void* ws, float* flat, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2 || !cffm_fwd_all_ok(s, B)) return CFFM_ERR_UNSUPPORTED;
+    cffm_theta_layout_t tl;
+    cffm_theta_layout(s, &tl);
+    const int64_t toff = ((int64_t)tl.n + 4 + 3) / 4 * 4;
+    hipError_t e = hipMemsetAsync(flat + tl.n, 0, (size_t)(toff - tl.n + (int64_t)s->M * (s->K + s->D + 1)) * 4, st);
+    if (e != hipSuccess) return (int)e;
+    const bool later = defer_rank(s, B);
+    if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later))) return rc;
+    if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, flat, false, nullptr, st, true, true,
+                            later ? ids : nullptr))) return rc;
+    return cffm_dp_tail_dense(s, B, ws, flat, st);
+}
+
 extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* tab_acc,
                                float* theta, float* theta_acc, float* grad, const int32_t* ids, const float* y,
                                int32_t B, void* ws, float* loss, void* stream) {

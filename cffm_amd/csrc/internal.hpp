@@ -47,6 +47,8 @@ int cffm_sparse_apply_impl(const cffm_shape_t* s, const cffm_tables_t* tab, cons
 // slab reduction (gradients only) and the packing of the rows + local loss sum, two roles of one launch
 int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws, float* grad, float* rows, bool with_run,
                  hipStream_t st);
+// dense-table variant of cffm_dp_tail: slab reduction ∥ scatter of this rank's summed row gradients into flat
+int cffm_dp_tail_dense(const cffm_shape_t* s, int32_t B, void* ws, float* flat, hipStream_t st);
 // rows[slot] = (id bits | dEi | dEo | dfb) for the all-gather of the data-parallel step; also copies the local
 // loss-term sum (scalars[0]) to *sum_dst
 int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const float* dEi, const float* dEo, const float* dfb,

@@ -500,6 +500,129 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
                                      B_ws, ls, st);
 }
 
+// ---- data-parallel step for SMALL vocabularies: the tables' gradients travel as one dense buffer --------------------
+// When M*(K+D+1) floats are fewer than what all ranks' row gradients add up to (frappe: 350 K floats against
+// N * 174 K), each rank scatters its duplicates-summed row gradients into a zeroed dense [M][K | D | 1] image that
+// rides behind the dense-parameter gradient in ONE all-reduce; afterwards every rank sweeps the whole tables.  Rows
+// nobody looked up carry an exact 0: acc + 0*0 and w - lr*0/sqrt(acc) leave them bit-identical, which is TF's sparse
+// semantics without a mask.  flat = [theta.n gradients | loss sum | pad to n4 | Gi M*K | Go M*D | Gfb M].
+static inline int64_t dp_dense_table_off(const cffm_theta_layout_t& tl) { return ((int64_t)tl.n + 4 + 3) / 4 * 4; }
+
+struct ScatterArgs {
+    const unsigned long long* keys;   // this rank's sorted keys
+    int64_t n;
+    int M, K, D, B;
+    const float *dEi, *dEo, *dfb, *sqerr;
+    float *Gi, *Go, *Gfb, *sum_dst, *scalars;
+};
+__device__ __forceinline__ void scatter_rows_body(int bid, const ScatterArgs& a, float* red) {
+    if (bid == 0) {                                  // role 0 of this range: loss-term sum of this rank, fixed order
+        float part = 0.f;
+        for (int i = threadIdx.x; i < a.B; i += 256) part += a.sqerr[i];
+        const float sum = block_sum(part, red);
+        if (threadIdx.x == 0) { a.sum_dst[0] = sum; a.scalars[0] = sum; }
+        return;
+    }
+    const int64_t pos = (int64_t)(bid - 1) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pos >= a.n) return;
+    const int id = (int)(a.keys[pos] >> 32);
+    if (pos > 0 && (int)(a.keys[pos - 1] >> 32) == id) return;
+    if (id < 0 || id >= a.M) return;
+    const int K = a.K, D = a.D, W = K + D + 1;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= W) continue;
+        float g = 0.f;
+        for (int64_t q = pos; q < a.n; ++q) {
+            const unsigned long long kq = a.keys[q];
+            if ((int)(kq >> 32) != id) break;
+            const int64_t sl = (int64_t)(kq & 0xffffffffull);
+            g += c < K ? a.dEi[sl * K + c] : (c < K + D ? a.dEo[sl * D + (c - K)] : a.dfb[sl]);
+        }
+        if (c < K) a.Gi[(int64_t)id * K + c] = g;
+        else if (c < K + D) a.Go[(int64_t)id * D + (c - K)] = g;
+        else a.Gfb[id] = g;
+    }
+}
+__global__ __launch_bounds__(256) void dp_tail_dense_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
+                                                            float* __restrict__ grad, int n_reduce, ScatterArgs sa) {
+    __shared__ float red[4];
+    if ((int)blockIdx.x < n_reduce) reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, nullptr, nullptr, 0.f);
+    else scatter_rows_body(blockIdx.x - n_reduce, sa, red);
+}
+
+int cffm_dp_tail_dense(const cffm_shape_t* s, int32_t B, void* ws, float* flat, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    const int64_t toff = dp_dense_table_off(tl);
+    ScatterArgs sa;
+    sa.keys = (const unsigned long long*)(w + wl.sort_vals); sa.n = (int64_t)B * s->F;
+    sa.M = s->M; sa.K = s->K; sa.D = s->D; sa.B = B;
+    sa.dEi = (const float*)(w + wl.dEi); sa.dEo = (const float*)(w + wl.dEo); sa.dfb = (const float*)(w + wl.dfb);
+    sa.sqerr = (const float*)(w + wl.sqerr);
+    sa.Gi = flat + toff; sa.Go = sa.Gi + (int64_t)s->M * s->K; sa.Gfb = sa.Go + (int64_t)s->M * s->D;
+    sa.sum_dst = flat + tl.n; sa.scalars = (float*)(w + wl.scalars);
+    const int n_reduce = (int)((tl.n + 255) / 256);
+    const int n_scatter = 1 + (int)((sa.n + 3) / 4);
+    hipLaunchKernelGGL(dp_tail_dense_kernel, dim3(n_reduce + n_scatter), dim3(256), 0, st, (const float*)(w + wl.gpart),
+                       (int64_t)tl.n, sp, flat, n_reduce, sa);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+struct DenseTableArgs { float *w[3], *a[3]; const float* g[3]; int64_t n[3]; };
+__global__ __launch_bounds__(256) void dp_apply_dense_kernel(float* __restrict__ v, float* __restrict__ acc, const float* __restrict__ grad,
+                                                             int64_t n, float lr, LateScale ls, float* __restrict__ loss_out, int n_dense,
+                                                             DenseTableArgs t) {
+    if ((int)blockIdx.x < n_dense) { dense_adagrad_body(blockIdx.x, v, acc, grad, n, lr, ls, loss_out); return; }
+    int64_t i = (int64_t)(blockIdx.x - n_dense) * 256 + threadIdx.x;
+    const float gs = late_scale(ls);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (i < t.n[k]) {
+            const float g = t.g[k][i] * gs;
+            const float a = t.a[k][i] + g * g;               // g == 0 (row not looked up by any rank): a and w unchanged
+            t.a[k][i] = a;
+            t.w[k][i] -= lr * g / sqrtf(a);
+            return;
+        }
+        i -= t.n[k];
+    }
+}
+
+extern "C" int64_t cffm_dp_dense_floats(const cffm_shape_t* s) {
+    if (check_shape(s)) return -1;
+    cffm_theta_layout_t tl;
+    cffm_theta_layout(s, &tl);
+    return dp_dense_table_off(tl) + (int64_t)s->M * (s->K + s->D + 1);
+}
+
+extern "C" int cffm_dp_apply_dense(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, float* theta,
+                                   float* theta_acc, const float* flat_sum, int64_t B_global, float* loss_out, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+    cffm_theta_layout_t tl;
+    cffm_theta_layout(s, &tl);
+    const int64_t toff = dp_dense_table_off(tl);
+    LateScale ls = {flat_sum + tl.n, 1.f / (float)B_global, s->loss == CFFM_LOSS_SQUARE_RMSE ? 1 : 0};
+    DenseTableArgs t;
+    t.w[0] = tab->inner_emb; t.w[1] = tab->outer_emb; t.w[2] = tab->feat_bias;
+    t.a[0] = acc->inner_emb; t.a[1] = acc->outer_emb; t.a[2] = acc->feat_bias;
+    t.n[0] = (int64_t)s->M * s->K; t.n[1] = (int64_t)s->M * s->D; t.n[2] = s->M;
+    t.g[0] = flat_sum + toff; t.g[1] = t.g[0] + t.n[0]; t.g[2] = t.g[1] + t.n[1];
+    const int n_dense = (int)((tl.n + 255) / 256);
+    const int64_t nt = t.n[0] + t.n[1] + t.n[2];
+    hipLaunchKernelGGL(dp_apply_dense_kernel, dim3((unsigned)(n_dense + (nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, theta,
+                       theta_acc, flat_sum, (int64_t)tl.n, s->lr, ls, loss_out, n_dense, t);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- regularised square loss (CFFM.py:489-491): the l2 terms make the table gradients dense ------------------------
 // 1) segment heads of the sorted keys write the duplicates-summed row gradients into zeroed dense buffers Gi/Go and
 //    apply the (still sparse) feature_bias update; 2) a dense sweep applies Adagrad with g = G + lamda * w to every row.

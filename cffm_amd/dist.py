@@ -10,7 +10,10 @@ over the GLOBAL batch, CFFM.py:493) and the parameter gradients:
   3. ONE all-reduce (sum) of the flat dense gradient with the local loss-term sum in a spare slot
      (41 K floats at frappe, 5 M at F=32)
   4. 1/L = rsqrt(sum/Bg + 1e-10) is applied to the summed gradients inside the update kernels
-  5. sparse tables, two modes:
+  5. sparse tables, three modes:
+       dense image (small vocabularies, e.g. frappe from 3 ranks up): every rank scatters its duplicates-summed row gradients
+           into a zeroed dense [M][K|D|1] image that rides in the SAME all-reduce as the dense gradients; one collective
+           per step and a plain sweep of the tables afterwards (rows nobody looked up carry an exact 0 and stay put);
        replicated (default while the tables fit one GPU):  ONE all-gather of packed (id, row gradients); every rank then
            runs the same sorted segment-sum + Adagrad over the Bg*F rows, so the replicas stay bit-identical;
        row-sharded (``ShardedTables``, vocabulary beyond one GPU's HBM): ids all-to-all to the owner
@@ -35,7 +38,7 @@ class DataParallelStep(object):
 
     Every rank applies the same update to its replica, so the replicas stay bit-identical."""
 
-    def __init__(self, compute, group=None, use_graph=False):
+    def __init__(self, compute, group=None, use_graph=False, mode='auto'):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
@@ -46,11 +49,19 @@ class DataParallelStep(object):
         # costs ~200 us of host time (two torch.distributed calls), more than its ~150 us of GPU work at frappe.
         self.use_graph = use_graph
         self._graphs = {}
+        self.mode = mode              # 'auto' | 'dense' (table gradients as a dense image, one all-reduce) | 'gather'
 
     def _eager(self, ids, y):
         c = self.c
         B = ids.shape[0]
         Bg = B * self.world
+        dense = self.mode != 'gather' and hasattr(c, 'dp_dense_ok') and \
+            c.dp_dense_ok(B, self.world if self.mode == 'auto' else 1 << 20)
+        if dense:
+            # small vocabulary: dense gradients and the dense image of the table gradients in ONE all-reduce
+            flat = c.dp_local_dense(ids, y, B, Bg)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return c.dp_apply_dense(flat, Bg)
         if hasattr(c, 'dp_local'):
             grad, rows = c.dp_local(ids, y, B, Bg)
         else:

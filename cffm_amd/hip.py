@@ -73,6 +73,9 @@ PROTOTYPES = {
     'cffm_backward_unscaled': (C.c_int, [_SH, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_dp_apply': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, _P, C.c_int32, _P]),
     'cffm_dp_runs_ok': (C.c_int, [_SH, C.c_int32]),
+    'cffm_dp_dense_floats': (C.c_int64, [_SH]),
+    'cffm_dp_local_dense': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    'cffm_dp_apply_dense': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, _P]),
     'cffm_dp_local': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), _P]),

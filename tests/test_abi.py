@@ -23,7 +23,7 @@ def lib():
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
     header = open(os.path.join(ROOT, 'include', 'cffm_hip.h')).read()
-    declared = set(re.findall(r'^\s*(?:int|const char \*)\s*\*?\s*(cffm_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t|const char \*)\s*\*?\s*(cffm_\w+)\s*\(', header, flags=re.M))
     assert len(declared) >= 20
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
     for name in declared:

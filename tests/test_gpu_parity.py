@@ -323,22 +323,40 @@ def test_full_size_configs(name):
     assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
 
 
-@pytest.mark.parametrize('route', ['runs', 'rows'])
+@pytest.mark.parametrize('route', ['runs', 'rows', 'dense'])
 def test_data_parallel_halves_on_one_gpu(route):
     """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run the local half
     of the step on the two halves of a batch, the test plays the role of the two collectives (sum of the flat gradient
     buffers, concatenation of what would be all-gathered), and cffm_dp_apply on each replica must reproduce one oracle
     step on the whole batch - including duplicates of an id that sit on different ranks.
     route 'runs': cffm_dp_local blocks (rows + each rank's sorted key run, merged by rank in cffm_dp_apply);
-    route 'rows': cffm_forward + cffm_backward_unscaled rows in any order (sorted inside cffm_dp_apply)."""
+    route 'rows': cffm_forward + cffm_backward_unscaled rows in any order (sorted inside cffm_dp_apply);
+    route 'dense': cffm_dp_local_dense buffers (dense gradients + dense image of the table gradients), ONE sum, then
+    cffm_dp_apply_dense."""
     cfg, p32, X, y = make_case('bookx-relu')
     B = X.shape[0]
     h = B // 2
     engines = [engine_for(cfg, p32), engine_for(cfg, p32)]
     ids = [torch.from_numpy(X[:h]).cuda(), torch.from_numpy(X[h:]).cuda()]
     ys = [torch.from_numpy(y[:h]).cuda(), torch.from_numpy(y[h:]).cuda()]
+    p64 = to64(p32)
+    grads_ref = oracle_dense_grads(p64, X, y, cfg)
+    acc = orc.init_accumulators(p64)
+    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
+    outs = []
+    if route == 'dense':
+        flats = [e.dp_local_dense(i, t, h, B).clone() for e, i, t in zip(engines, ids, ys)]
+        torch.cuda.synchronize()
+        fsum = flats[0] + flats[1]                   # the all-reduce
+        for e in engines:
+            loss = e.dp_apply_dense(fsum.clone(), B)
+            torch.cuda.synchronize()
+            close(loss.cpu().numpy(), [L], 'loss')
+            outs.append(e.export_params())
     grads, rows = [], []
     for e, i, t in zip(engines, ids, ys):
+        if route == 'dense':
+            break
         if route == 'runs':
             g, r = e.dp_local(i, t, h, B)
         else:
@@ -346,14 +364,11 @@ def test_data_parallel_halves_on_one_gpu(route):
             g, r = e.backward_unscaled(i, t, h, B)
         grads.append(g.clone()); rows.append(r.clone())
     torch.cuda.synchronize()
-    gsum = grads[0] + grads[1]                       # all-reduce
-    rall = torch.cat(rows, dim=0).contiguous()       # all-gather
-    p64 = to64(p32)
-    grads_ref = oracle_dense_grads(p64, X, y, cfg)
-    acc = orc.init_accumulators(p64)
-    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
-    outs = []
     for e in engines:
+        if route == 'dense':
+            break
+        gsum = grads[0] + grads[1]                       # all-reduce
+        rall = torch.cat(rows, dim=0).contiguous()       # all-gather
         loss = e.dp_apply(gsum.clone(), rall, B, 2 if route == 'runs' else 0)
         torch.cuda.synchronize()
         close(loss.cpu().numpy(), [L], 'loss')
