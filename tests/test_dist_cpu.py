@@ -104,6 +104,46 @@ class OracleCompute(object):
         return torch.tensor([L])
 
 
+class DenseOracleCompute(OracleCompute):
+    """The dense-image route of DataParallelStep (small vocabularies): one flat buffer, one all-reduce."""
+
+    def dp_dense_ok(self, B, world):
+        return True
+
+    def dp_local_dense(self, ids, y, B, Bg):
+        self.forward(ids, y)
+        dout = (self.out - y.numpy()) / Bg
+        g = orc.backward(self.p, self.cache, dout, self.cfg)
+        X = self.X.reshape(-1)
+        parts = [np.asarray(g[k]).reshape(-1) for k in self.names] + [[float(self.sc[0])]]
+        for name, key in (('inner_embeddings', 'd_inner_rows'), ('outer_embeddings', 'd_outer_rows'), ('feature_bias', 'd_bias_rows')):
+            t = np.zeros(self.p[name].shape)
+            np.add.at(t, X, g[key].reshape(len(X), -1).reshape((len(X),) + self.p[name].shape[1:]))
+            parts.append(t.reshape(-1))
+        return torch.from_numpy(np.concatenate(parts))
+
+    def dp_apply_dense(self, flat, Bg):
+        f = flat.numpy()
+        n = sum(self.sizes)
+        L = np.sqrt(f[n] / Bg + 1e-10)
+        o = 0
+        for k, sz in zip(self.names, self.sizes):
+            gk = (f[o:o + sz] / L).reshape(self.p[k].shape)
+            o += sz
+            a = self.acc[k] + gk * gk
+            self.acc[k] = a
+            self.p[k] = self.p[k] - self.cfg.lr * gk / np.sqrt(a)
+        o = n + 1
+        for name in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+            sz = self.p[name].size
+            gk = (f[o:o + sz] / L).reshape(self.p[name].shape)
+            o += sz
+            a = self.acc[name] + gk * gk                       # rows with gk == 0 keep acc and value
+            self.acc[name] = a
+            self.p[name] = self.p[name] - self.cfg.lr * gk / np.sqrt(a)
+        return torch.tensor([L])
+
+
 class ShardedOracleCompute(OracleCompute):
     """The same stand-in over a LOCAL table shard (rows rank, rank+G, ...) for ShardedStep."""
 
@@ -145,10 +185,10 @@ def _case():
     return cfg, p, X, y
 
 
-def _dp_worker(rank, world):
+def _dp_worker(rank, world, dense=False):
     from cffm_amd.dist import DataParallelStep
     cfg, p, X, y = _case()
-    comp = OracleCompute(cfg, p)
+    comp = (DenseOracleCompute if dense else OracleCompute)(cfg, p)
     step = DataParallelStep(comp)
     per = X.shape[0] // world
     sl = slice(rank * per, rank * per + per)
@@ -156,9 +196,9 @@ def _dp_worker(rank, world):
     return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_data_parallel_step_equals_single_process_step(world):
-    res = _run(_dp_worker, world)
+@pytest.mark.parametrize('world,dense', [(2, False), (4, False), (2, True)])
+def test_data_parallel_step_equals_single_process_step(world, dense):
+    res = _run(_dp_worker, world, dense)
     cfg, p, X, y = _case()
     acc = orc.init_accumulators(p)
     L, _ = orc.train_step(p, acc, X, y, cfg)
