@@ -1937,6 +1937,111 @@ static int launch_conv_fwd_rows(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+// Layer 0 in factorised form for WIDE filters (Pp > 64, e.g. F = 32: P = 496): the T planes of all channels no longer
+// fit LDS (4 MB per example), so a workgroup takes one example, ONE tile of 16 output channels q0 .. q0+15 and ONE tile
+// of 16 output columns x0 .. x0+15 (T[.., x, q] depends on nothing outside its (x, q)):
+//   step 1  T[dh][i][x][q] = sum_{dw, j>i} E_j[2x+dw] * W[dh,dw,(i,j),q]     2(F-1) units, K = 2(F-1-i)
+//   step 2  C[y][x][q]     = relu(b[q] + sum_{dh,i} E_i[2y+dh] * T[dh][i][x][q])        S/16 row tiles, K = 2F
+// 15.7x fewer MFMAs than the direct contraction at F = 32, D = 64 (128 MFLOP against 2,015 per example).  W fragments come
+// straight from L2 (a 16-channel column slice of the filter, 127 KB, shared by every example of the tile: the grid is
+// tile-major); T (2F planes of 16 x 16, 70 KB: two workgroups per CU) and the embedding tile live in LDS.
+#define C0T_MAXKS 16      // k-steps of one step-1 unit: 2(F-1)/4 <= 16 for F <= 32
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArgs a) {
+    constexpr int NTH = 64 * NW, XQ = 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, PpT = a.Pp;
+    constexpr int TP = 16 * 16 + 16;
+    float* T = reinterpret_cast<float*>(smem);                 // [2F][TP]
+    float* Es = T + 2 * F * TP;                                 // [F][Dp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int b = bid % a.B; bid /= a.B;
+    const int xt = bid % RT, qt = bid / RT, q0 = qt * 16, x0 = xt * 16;
+    {
+        const float* e = a.in + (int64_t)b * F * D;
+        const float invD = 1.f / (float)D;
+        for (int i = tid; i < F * D; i += NTH) {
+            const int f = fast_div(i, invD), d = i - f * D;
+            Es[f * Dp + d] = e[i];
+        }
+    }
+    lds_barrier();
+    // ---- step 1 -----------------------------------------------------------------------------------------------------
+    const int units = 2 * (F - 1);
+    for (int u = wave; u < units; u += NW) {
+        const int i = u % (F - 1), dh = u / (F - 1);
+        const int nj = F - 1 - i, K = 2 * nj;                   // k = dw * nj + (j - i - 1)
+        const int base = i * (2 * F - i - 1) / 2;
+        const int x = x0 + r;
+        float bw[C0T_MAXKS], av[C0T_MAXKS];
+#pragma unroll
+        for (int ks = 0; ks < C0T_MAXKS; ++ks) {                // every fragment of the unit is requested up front:
+            const int k = 4 * ks + kk;                          // 16 independent L2 loads and 16 independent LDS reads
+            const bool ok = k < K;
+            const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
+            bw[ks] = ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f;
+            av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C0T_MAXKS; ++ks)
+            if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);  // wave-uniform skip of the empty k-steps
+        float* tp = T + (dh * F + i) * TP + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tp[(kk * 4 + j) * 16] = acc[j];
+    }
+    for (int e = tid; e < 2 * 16 * 16; e += NTH) {            // planes (dh, F-1) have no pairs
+        const int dh = e / 256, o = e - dh * 256;
+        T[(dh * F + F - 1) * TP + o] = 0.f;
+    }
+    lds_barrier();
+    // ---- step 2 -----------------------------------------------------------------------------------------------------
+    const int K2 = 2 * F, ks2 = (K2 + 3) / 4;
+    const float bias = a.bias[q0 + r];
+    for (int rt = 0; rt < RT; ++rt) {
+        const int y = rt * 16 + r;
+        const int xg = wave * XQ;                               // NW * XQ = 16 columns of this tile
+        f32x4 acc[XQ];
+#pragma unroll
+        for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < ks2; ++s2) {
+            const int k = 4 * s2 + kk;
+            const bool ok = k < K2;
+            const int dh = (ok && k >= F) ? 1 : 0, i = ok ? k - dh * F : 0;
+            const float av = ok ? Es[i * Dp + 2 * y + dh] : 0.f;
+            const float* tb = T + (ok ? k : 0) * TP + xg * 16 + r;
+#pragma unroll
+            for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = mfma16(av, ok ? tb[q4 * 16] : 0.f, acc[q4]);
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < XQ; ++q4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = rt * 16 + kk * 4 + j;
+                a.out[(((int64_t)b * S + yy) * S + x0 + xg + q4) * PpT + q0 + r] = fmaxf(acc[q4][j] + bias, 0.f);
+            }
+    }
+}
+
+static inline bool conv0_fact_tile_ok(const Geo& g) {
+    const int S = g.D / 2;
+    return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
+}
+
+static int launch_conv0_fact_tile_fwd(const ConvArgs& a, hipStream_t st) {
+    constexpr int NW = 4;
+    const int S = a.D / 2;
+    const size_t lds = (size_t)(2 * a.F * (16 * 16 + 16) + a.F * (a.D + 1)) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_fwd_kernel<NW>, lds);
+    if (rc) return rc;
+    const int64_t grid = (int64_t)a.B * (a.Pp / 16) * (S / 16);
+    if (grid > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv0_fact_tile_fwd_kernel<NW>), dim3((unsigned)grid), dim3(64 * NW), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int NT>
 static int launch_conv0_fact_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int PP = NT * 16;
@@ -2096,6 +2201,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         }
         return rc;
     }
+    if (l == 0 && conv0_fact_tile_ok(g)) return launch_conv0_fact_tile_fwd(a, st);   // rank-1 input channels: factorised, channel-tiled
     pick_nt(g.Pp / 16, &nblk, &NT);
     const bool big = a.Mtot >= 128 * 256;
     if (l == 0) {
