@@ -2024,6 +2024,152 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
     }
 }
 
+// Weight / bias gradient of layer 0 for wide filters in factorised form (the direct contraction is 2,015 MFLOP per
+// example at F32 D64, this is 128):
+//   dT[dh][i][x][q]        = sum_y E_i[2y+dh] * dC[y][x][q]                  rows (dh,i), K = y, cols (x,q)
+//   dW[dh][dw][(i,j)][q]  += sum_x E_j[2x+dw] * dT[dh][i][x][q]              rows (dw,j>i), K = x, cols q
+// Workgroup = (16-channel tile q0, group g of 16 (dh,i) rows, gradient slab): it walks the examples of its slab and their
+// S/16 column tiles, keeps the dW blocks of its 16 units in registers (<= 4 row tiles each, 4 units per wavefront) and
+// writes them once.  dC tile [S][16][16] and dT [16][16][16] live in LDS (41 KB: two workgroups per CU).
+template <int SMAX>
+__global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs a, int nslab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, PpT = a.Pp, P = a.P, G = (2 * F + 15) / 16;
+    float* Es = reinterpret_cast<float*>(smem);                // [F][Dp]
+    float* dCt = Es + (F * Dp + 3) / 4 * 4;                    // [S][16 x][16 q]
+    float* dTg = dCt + SMAX * 256;                              // [16 m][16 x][16 q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int slab = bid % nslab; bid /= nslab;
+    const int g = bid % G, qt = bid / G, q0 = qt * 16;
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride;
+    float* sb = a.slabB + (int64_t)slab * a.slabB_stride;
+    // this wave's four units (dh, i) and the A-row identity of this lane for phase C
+    const int mC = g * 16 + r;                                  // phase C row of this lane
+    const bool mC_ok = mC < 2 * F;
+    const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+    f32x4 accD[4][4];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) accD[u4][t4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                          // bias partial of channel q0 + (tid & 15), rows tid >> 4 (g == 0 only)
+    for (int b = slab; b < a.B; b += nslab) {
+        __syncthreads();                                       // previous example fully consumed
+        {
+            const float* e = a.in + (int64_t)b * F * D;
+            const float invD = 1.f / (float)D;
+            for (int i = tid; i < F * D; i += 256) {
+                const int f = fast_div(i, invD), d = i - f * D;
+                Es[f * Dp + d] = e[i];
+            }
+        }
+        for (int xt = 0; xt < RT; ++xt) {
+            const int x0 = xt * 16;
+            if (xt > 0) __syncthreads();                       // dCt / dTg of the previous column tile consumed
+            // dC[b][y][x0 + x][q0 .. q0+15] -> dCt[y][x][q] : 64-byte pieces
+            for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {
+                const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
+                const float4 v = *reinterpret_cast<const float4*>(a.dC + (((int64_t)b * S + y) * S + x0 + x) * PpT + q0 + 4 * q4);
+                *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) = v;
+            }
+            __syncthreads();
+            if (g == 0) {                                      // db[q] += sum_{y,x} dC: thread (q = tid & 15, part = tid >> 4)
+                const int q = tid & 15, part = tid >> 4;
+                for (int e = part; e < S * 16; e += 16) bsum += dCt[e * 16 + q];
+            }
+            // ---- phase C: dT rows mC (this group), wave's x columns 4*wave .. 4*wave+3 ------------------------------
+            {
+                f32x4 acc[4];
+#pragma unroll
+                for (int xl = 0; xl < 4; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int s4 = 0; s4 < S / 4; ++s4) {
+                    const int y = 4 * s4 + kk;
+                    const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
+#pragma unroll
+                    for (int xl = 0; xl < 4; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + 4 * wave + xl) * 16 + r], acc[xl]);
+                }
+#pragma unroll
+                for (int xl = 0; xl < 4; ++xl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + 4 * wave + xl) * 16 + r] = acc[xl][j];
+            }
+            __syncthreads();
+            // ---- phase D: the wave's four units -----------------------------------------------------------------------
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int ml = wave * 4 + u4, m = g * 16 + ml;
+                if (m >= 2 * F) continue;
+                const int dh = m >= F ? 1 : 0, i = m - dh * F;
+                (void)dh;
+                const int nj = F - 1 - i, K2 = 2 * nj;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    if (t4 * 16 >= K2) continue;
+                    const int m2 = t4 * 16 + r;
+                    const bool ok = m2 < K2;
+                    const int dw = (ok && m2 >= nj) ? 1 : 0, jj = ok ? m2 - dw * nj : 0;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int x = 4 * s4 + kk;
+                        const float av = ok ? Es[(i + 1 + jj) * Dp + 2 * (x0 + x) + dw] : 0.f;
+                        accD[u4][t4] = mfma16(av, dTg[(ml * 16 + x) * 16 + r], accD[u4][t4]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's part of the slab ------------------------------------------------------------------
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+        const int m = g * 16 + wave * 4 + u4;
+        if (m >= 2 * F) continue;
+        const int dh = m >= F ? 1 : 0, i = m - dh * F;
+        const int nj = F - 1 - i, K2 = 2 * nj, base = i * (2 * F - i - 1) / 2;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            if (t4 * 16 >= K2) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m2 = t4 * 16 + kk * 4 + j;
+                if (m2 < K2) {
+                    const int dw = m2 >= nj ? 1 : 0, jj = m2 - dw * nj;
+                    sw[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] = accD[u4][t4][j];
+                }
+            }
+        }
+    }
+    if (g == 0) {
+        // rows of padded pairs (p >= P) are never produced: they must read as zeros in the reduction
+        for (int e = tid; e < 4 * (PpT - P) * 16; e += 256) {
+            const int q = e & 15, rest = e >> 4, p = P + rest % (PpT - P), tap = rest / (PpT - P);
+            sw[((int64_t)tap * PpT + p) * PpT + q0 + q] = 0.f;
+        }
+        __syncthreads();
+        float* red = dTg;                                      // [16 parts][16 q]
+        red[(tid >> 4) * 16 + (tid & 15)] = bsum;
+        __syncthreads();
+        if (tid < 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int part = 0; part < 16; ++part) v += red[part * 16 + tid];
+            sb[q0 + tid] = v;
+        }
+    }
+}
+
+static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream_t st) {
+    const int S = a.D / 2, G = (2 * a.F + 15) / 16;
+    if (S > 32) return CFFM_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 16 * 256) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_wgrad_kernel<32>, lds);
+    if (rc) return rc;
+    const int64_t grid = (int64_t)(a.Pp / 16) * G * nslab;
+    hipLaunchKernelGGL((conv0_fact_tile_wgrad_kernel<32>), dim3((unsigned)grid), dim3(256), lds, st, a, nslab);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline bool conv0_fact_tile_ok(const Geo& g) {
     const int S = g.D / 2;
     return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
@@ -2361,7 +2507,8 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             if (rc) return rc;
         } else {
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
-        if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
+        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) { rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st); }
+        else if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
         else { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, false>(a, st))); }
         if (rc) return rc;
         }
