@@ -2170,6 +2170,195 @@ static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream
     return 0;
 }
 
+// Input gradient of layer 0 (dEo) for wide filters in factorised form.  With T and dT as above,
+//   dEi[(dh,i)][y] = sum_{x,q} dC[y][x][q] * T[dh][i][x][q]                              rows y, K = (x,q), cols (dh,i)
+//   dEj[(dw,j)][x] = sum_{dh,i<j,q} W[dh,dw,(i,j),q] * dT[dh][i][x][q]                   rows (dw,j), K = q, cols x
+//   dEo[f][h]      = dEi[(h&1,f)][h>>1] + dEj[(h&1,f)][h>>1] + dt1[h]*R_f + Q_f           (s0 pool gradient in closed form)
+// One workgroup per example walks (group g of 16 (dh,i) rows) x (column tile) x (channel tile); per step it stages the
+// dC tile, recomputes the 16 T planes and the 16 dT planes of the group in LDS and feeds two accumulators that live in
+// registers across the walk: dEi of the group (K split over the wavefronts, summed at the end of the group) and dEj
+// (each wavefront sums its own four units, summed at the very end).  ~325 MFLOP per example at F32 D64 against 2,015.
+template <int SMAX>
+__global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, YT = S / 16, PpT = a.Pp, QT = PpT / 16, G = (2 * F + 15) / 16;
+    float* Es = reinterpret_cast<float*>(smem);                // [F][Dp]
+    float* dCt = Es + (F * Dp + 3) / 4 * 4;                    // [S][16 x][16 q]
+    float* Tg = dCt + SMAX * 256;                               // [16 m][16 x][16 q]
+    float* dTg = Tg + 4096;                                     // [16 m][16 x][16 q]
+    float* part = dTg + 4096;                                   // [4 waves][4 tiles][64 lanes][4]   cross-wave sums
+    float* dEi = part + 4 * 4 * 256;                            // [G*16][SMAX]    (n = dh*F + i, y)
+    float* dEj = dEi + 64 * SMAX;                               // [64][SMAX]      (n = dw*F + j, x)
+    float* rs = dEj + 64 * SMAX;                                // [F] row sums, [F] dots
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.x;
+    {
+        const float* e = a.Cprev + (int64_t)b * F * D;
+        const float invD = 1.f / (float)D;
+        for (int i = tid; i < F * D; i += 256) {
+            const int f = fast_div(i, invD), d = i - f * D;
+            Es[f * Dp + d] = e[i];
+        }
+    }
+    f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accE[xt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* dCb = a.dC + (int64_t)b * S * S * PpT;
+    for (int g = 0; g < G; ++g) {
+        const int mC = g * 16 + r;                              // phase C row of this lane
+        const bool mC_ok = mC < 2 * F;
+        const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+        f32x4 accB[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // [y tile] x (16 rows of the group)
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            if (xt >= RT) continue;
+            const int x0 = xt * 16;
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q0 = qt * 16;
+                __syncthreads();                               // dCt / Tg / dTg of the previous step consumed
+                for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {
+                    const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
+                    *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) =
+                        *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
+                }
+                // ---- A: T planes of this wave's four units -------------------------------------------------------
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    const int ml = wave * 4 + u4, m = g * 16 + ml;
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (m < 2 * F) {
+                        const int dh = m >= F ? 1 : 0, i = m - dh * F;
+                        const int nj = F - 1 - i, K = 2 * nj, base = i * (2 * F - i - 1) / 2;
+                        float bw[C0T_MAXKS], av[C0T_MAXKS];
+#pragma unroll
+                        for (int ks = 0; ks < C0T_MAXKS; ++ks) {
+                            const int k = 4 * ks + kk;
+                            const bool ok = k < K;
+                            const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
+                            bw[ks] = ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f;
+                            av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * (x0 + r) + dw] : 0.f;
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < C0T_MAXKS; ++ks)
+                            if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Tg[(ml * 16 + kk * 4 + j) * 16 + r] = acc[j];
+                }
+                __syncthreads();                               // dCt staged (and Tg written)
+                // ---- C: dT planes of the group, wave's columns 4*wave .. 4*wave+3 ------------------------------------
+                {
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int xl = 0; xl < 4; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int s4 = 0; s4 < S / 4; ++s4) {
+                        const int y = 4 * s4 + kk;
+                        const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
+#pragma unroll
+                        for (int xl = 0; xl < 4; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + 4 * wave + xl) * 16 + r], acc[xl]);
+                    }
+#pragma unroll
+                    for (int xl = 0; xl < 4; ++xl)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + 4 * wave + xl) * 16 + r] = acc[xl][j];
+                }
+                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, 16 per wave), cols m ---------------
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int kf = 4 * (wave * 16 + ks) + kk, x = kf >> 4, q = kf & 15;
+                    const float bv = Tg[(r * 16 + x) * 16 + q];
+#pragma unroll
+                    for (int yt = 0; yt < 2; ++yt)
+                        if (yt < YT) accB[yt] = mfma16(dCt[((yt * 16 + r) * 16 + x) * 16 + q], bv, accB[yt]);
+                }
+                __syncthreads();                               // dTg written
+                // ---- E: dEj rows (dw,j), K = q, cols x: this wave's four units ----------------------------------------
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    const int ml = wave * 4 + u4, m = g * 16 + ml;
+                    if (m >= 2 * F) continue;
+                    const int dh = m >= F ? 1 : 0, i = m - dh * F, base = i * (2 * F - i - 1) / 2;
+                    const float4 bv = *reinterpret_cast<const float4*>(dTg + (ml * 16 + r) * 16 + 4 * kk);   // [k = q = 4kk+t][n = x = r]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int n = t * 16 + r, dw = n >= F ? 1 : 0, j = n - dw * F;
+                        // the tile is empty when none of its rows has j > i (wave-uniform test on the tile's last rows)
+                        const int jmax_lo = min(F - 1, t * 16 + 15), jmax_hi = t * 16 + 15 - F;
+                        const bool any = (t * 16 < F && jmax_lo > i) || (t * 16 + 15 >= F && jmax_hi > i && t * 16 < 2 * F);
+                        if (!any) continue;
+                        const bool ok = n < 2 * F && j > i;
+                        const float4 wv = ok ? *reinterpret_cast<const float4*>(a.W + ((int64_t)(dh * 2 + dw) * PpT + base + j - i - 1) * PpT + q0 + 4 * kk)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                        accE[xt][t] = mfma16(wv.x, bv.x, accE[xt][t]);
+                        accE[xt][t] = mfma16(wv.y, bv.y, accE[xt][t]);
+                        accE[xt][t] = mfma16(wv.z, bv.z, accE[xt][t]);
+                        accE[xt][t] = mfma16(wv.w, bv.w, accE[xt][t]);
+                    }
+                }
+            }
+        }
+        // ---- dEi of this group: sum the four wavefronts' K slices --------------------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (int yt = 0; yt < 2; ++yt)
+            *reinterpret_cast<f32x4*>(part + ((wave * 4 + yt) * 64 + lane) * 4) = accB[yt];
+        __syncthreads();
+        for (int e = tid; e < YT * 256; e += 256) {              // e = (yt, lane, j)
+            const int j = e & 3, ln = (e >> 2) & 63, yt = e >> 8;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += part[((w * 4 + yt) * 64 + ln) * 4 + j];
+            const int y = yt * 16 + (ln >> 4) * 4 + j, mm = g * 16 + (ln & 15);          // D layout: row y, col m
+            dEi[mm * SMAX + y] = v;
+        }
+    }
+    // ---- dEj: sum the four wavefronts' unit subsets -----------------------------------------------------------------
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+        if (xt >= RT) continue;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part + ((wave * 4 + t) * 64 + lane) * 4) = accE[xt][t];
+        __syncthreads();
+        for (int e = tid; e < 4 * 256; e += 256) {              // e = (t, lane, j)
+            const int j = e & 3, ln = (e >> 2) & 63, t = e >> 8;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += part[((w * 4 + t) * 64 + ln) * 4 + j];
+            const int n = t * 16 + (ln >> 4) * 4 + j, x = xt * 16 + (ln & 15);           // D layout: row (dw,j), col x
+            dEj[n * SMAX + x] = v;
+        }
+    }
+    if (tid < 2 * F) {                                           // row sums and <ds0, E[f]> for the closed-form s0 terms
+        const int f = tid % F;
+        float sacc = 0.f;
+        if (tid < F) { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h]; }
+        else { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h] * a.dt1[(int64_t)b * a.t1w + h]; }
+        rs[tid] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < F * D; e += 256) {
+        const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
+        float R = 0.f, Q = 0.f;
+        for (int j = f + 1; j < F; ++j) R += rs[j];
+        for (int i = 0; i < f; ++i) Q += rs[F + i];
+        a.dprev[(int64_t)b * F * D + e] = (dEi[(lo * F + f) * SMAX + hh] + dEj[(lo * F + f) * SMAX + hh])
+                                          + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+    }
+}
+
+static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
+    const int S = a.D / 2;
+    if (S > 32 || 2 * a.F > 64) return CFFM_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 4096 + 4096 + 4 * 4 * 256 + 64 * 32 + 64 * 32 + 2 * a.F) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_dgrad_kernel<32>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv0_fact_tile_dgrad_kernel<32>), dim3(a.B), dim3(256), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline bool conv0_fact_tile_ok(const Geo& g) {
     const int S = g.D / 2;
     return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
@@ -2536,6 +2725,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 1, false, 1>(a, st))); }
             return rc;
         }
+        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32 && 2 * g.F <= 64) return launch_conv0_fact_tile_dgrad(a, st);
         pick_nt(4 * g.Pp / 16, &nblk, &NT);
         const bool big = a.Mtot >= 128 * 256;
         if (l == 0) {
