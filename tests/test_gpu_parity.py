@@ -41,6 +41,10 @@ CASES = {
     # batch-size edges of the one-workgroup-per-example kernels: a single example, and B > 256 (workgroup 0 takes two)
     'b1-elu': dict(M=200, F=6, K=32, D=32, act='elu', B=1),
     'b257-relu': dict(M=900, F=6, K=32, D=32, act='relu', B=257),
+    # wide filters (Pp > 64): the tiled factorised layer-0 kernels at other field counts / map sizes, and F = 33 where the
+    # input-gradient kernel falls back to the direct contraction
+    'f20-d64-elu': dict(M=2000, F=20, K=16, D=64, act='elu', B=2),
+    'f33-d32-relu': dict(M=3000, F=33, K=8, D=32, act='relu', B=2),
 }
 
 
@@ -182,7 +186,7 @@ def test_backward_stages(name):
 
 
 @pytest.mark.parametrize('name', ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu',
-                                  'f12-d32-nolinatt', 'b1-elu', 'b257-relu'])
+                                  'f12-d32-nolinatt', 'b1-elu', 'b257-relu', 'f20-d64-elu', 'f33-d32-relu'])
 @pytest.mark.parametrize('trained_like', [True, False])
 def test_train_step_matches_oracle(name, trained_like):
     """One sess.run((loss, optimizer)): post-update parameters AND Adagrad accumulators of every
