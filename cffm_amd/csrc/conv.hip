@@ -2205,25 +2205,32 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
     for (int xt = 0; xt < 2; ++xt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) accE[xt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* dCb = a.dC + (int64_t)b * S * S * PpT;
-    for (int g = 0; g < G; ++g) {
-        const int mC = g * 16 + r;                              // phase C row of this lane
-        const bool mC_ok = mC < 2 * F;
-        const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
-        f32x4 accB[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // [y tile] x (16 rows of the group)
+    f32x4 accB[4][2];                                          // [row group g][y tile] x (16 rows of the group)
 #pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            if (xt >= RT) continue;
-            const int x0 = xt * 16;
-            for (int qt = 0; qt < QT; ++qt) {
-                const int q0 = qt * 16;
-                __syncthreads();                               // dCt / Tg / dTg of the previous step consumed
-                for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {
-                    const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
-                    *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) =
-                        *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
-                }
-                // ---- A: T planes of this wave's four units -------------------------------------------------------
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int yt = 0; yt < 2; ++yt) accB[g][yt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* dCb = a.dC + (int64_t)b * S * S * PpT;
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+        if (xt >= RT) continue;
+        const int x0 = xt * 16;
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q0 = qt * 16;
+            __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
+            for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {   // the dC tile is staged ONCE for the four row groups
+                const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
+                *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) =
+                    *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g >= G) continue;
+                const int mC = g * 16 + r;                      // phase C row of this lane
+                const bool mC_ok = mC < 2 * F;
+                const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+                if (g > 0) __syncthreads();                    // Tg / dTg of the previous group consumed
+                // ---- A: T planes of this wave's four units ---------------------------------------------------------
 #pragma unroll
                 for (int u4 = 0; u4 < 4; ++u4) {
                     const int ml = wave * 4 + u4, m = g * 16 + ml;
@@ -2247,8 +2254,8 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Tg[(ml * 16 + kk * 4 + j) * 16 + r] = acc[j];
                 }
-                __syncthreads();                               // dCt staged (and Tg written)
-                // ---- C: dT planes of the group, wave's columns 4*wave .. 4*wave+3 ------------------------------------
+                if (g == 0) __syncthreads();                   // dCt staged
+                // ---- C: dT planes of the group, wave's columns 4*wave .. 4*wave+3 --------------------------------------
                 {
                     f32x4 acc[4];
 #pragma unroll
@@ -2264,16 +2271,16 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + 4 * wave + xl) * 16 + r] = acc[xl][j];
                 }
-                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, 16 per wave), cols m ---------------
+                __syncthreads();                               // Tg and dTg written
+                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, 16 per wave), cols m -----------------
                 for (int ks = 0; ks < 16; ++ks) {
                     const int kf = 4 * (wave * 16 + ks) + kk, x = kf >> 4, q = kf & 15;
                     const float bv = Tg[(r * 16 + x) * 16 + q];
 #pragma unroll
                     for (int yt = 0; yt < 2; ++yt)
-                        if (yt < YT) accB[yt] = mfma16(dCt[((yt * 16 + r) * 16 + x) * 16 + q], bv, accB[yt]);
+                        if (yt < YT) accB[g][yt] = mfma16(dCt[((yt * 16 + r) * 16 + x) * 16 + q], bv, accB[g][yt]);
                 }
-                __syncthreads();                               // dTg written
-                // ---- E: dEj rows (dw,j), K = q, cols x: this wave's four units ----------------------------------------
+                // ---- E: dEj rows (dw,j), K = q, cols x: this wave's four units ------------------------------------------
 #pragma unroll
                 for (int u4 = 0; u4 < 4; ++u4) {
                     const int ml = wave * 4 + u4, m = g * 16 + ml;
@@ -2298,11 +2305,15 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
                 }
             }
         }
-        // ---- dEi of this group: sum the four wavefronts' K slices --------------------------------------------------
+    }
+    // ---- dEi: sum the four wavefronts' K slices, group by group -------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g >= G) continue;
         __syncthreads();
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt)
-            *reinterpret_cast<f32x4*>(part + ((wave * 4 + yt) * 64 + lane) * 4) = accB[yt];
+            *reinterpret_cast<f32x4*>(part + ((wave * 4 + yt) * 64 + lane) * 4) = accB[g][yt];
         __syncthreads();
         for (int e = tid; e < YT * 256; e += 256) {              // e = (yt, lane, j)
             const int j = e & 3, ln = (e >> 2) & 63, yt = e >> 8;
