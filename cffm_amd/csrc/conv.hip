@@ -2031,8 +2031,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
 // Workgroup = (16-channel tile q0, group g of 16 (dh,i) rows, gradient slab): it walks the examples of its slab and their
 // S/16 column tiles, keeps the dW blocks of its 16 units in registers (<= 4 row tiles each, 4 units per wavefront) and
 // writes them once.  dC tile [S][16][16] and dT [16][16][16] live in LDS (41 KB: two workgroups per CU).
-template <int SMAX>
-__global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs a, int nslab) {
+template <int SMAX, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs a, int nslab) {
+    constexpr int NTH = 64 * NW, UPW = 16 / NW;                // units (and phase-C columns) per wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, PpT = a.Pp, P = a.P, G = (2 * F + 15) / 16;
     float* Es = reinterpret_cast<float*>(smem);                // [F][Dp]
@@ -2048,9 +2049,9 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
     const int mC = g * 16 + r;                                  // phase C row of this lane
     const bool mC_ok = mC < 2 * F;
     const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
-    f32x4 accD[4][4];
+    f32x4 accD[UPW][4];
 #pragma unroll
-    for (int u4 = 0; u4 < 4; ++u4)
+    for (int u4 = 0; u4 < UPW; ++u4)
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) accD[u4][t4] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;                                          // bias partial of channel q0 + (tid & 15), rows tid >> 4 (g == 0 only)
@@ -2059,7 +2060,7 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
         {
             const float* e = a.in + (int64_t)b * F * D;
             const float invD = 1.f / (float)D;
-            for (int i = tid; i < F * D; i += 256) {
+            for (int i = tid; i < F * D; i += NTH) {
                 const int f = fast_div(i, invD), d = i - f * D;
                 Es[f * Dp + d] = e[i];
             }
@@ -2068,7 +2069,7 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
             const int x0 = xt * 16;
             if (xt > 0) __syncthreads();                       // dCt / dTg of the previous column tile consumed
             // dC[b][y][x0 + x][q0 .. q0+15] -> dCt[y][x][q] : 64-byte pieces
-            for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {
+            for (int e4 = tid; e4 < S * 16 * 4; e4 += NTH) {
                 const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
                 const float4 v = *reinterpret_cast<const float4*>(a.dC + (((int64_t)b * S + y) * S + x0 + x) * PpT + q0 + 4 * q4);
                 *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) = v;
@@ -2076,29 +2077,29 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
             __syncthreads();
             if (g == 0) {                                      // db[q] += sum_{y,x} dC: thread (q = tid & 15, part = tid >> 4)
                 const int q = tid & 15, part = tid >> 4;
-                for (int e = part; e < S * 16; e += 16) bsum += dCt[e * 16 + q];
+                for (int e = part; e < S * 16; e += NTH / 16) bsum += dCt[e * 16 + q];
             }
             // ---- phase C: dT rows mC (this group), wave's x columns 4*wave .. 4*wave+3 ------------------------------
             {
-                f32x4 acc[4];
+                f32x4 acc[UPW];
 #pragma unroll
-                for (int xl = 0; xl < 4; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int xl = 0; xl < UPW; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 for (int s4 = 0; s4 < S / 4; ++s4) {
                     const int y = 4 * s4 + kk;
                     const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
 #pragma unroll
-                    for (int xl = 0; xl < 4; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + 4 * wave + xl) * 16 + r], acc[xl]);
+                    for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + UPW * wave + xl) * 16 + r], acc[xl]);
                 }
 #pragma unroll
-                for (int xl = 0; xl < 4; ++xl)
+                for (int xl = 0; xl < UPW; ++xl)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + 4 * wave + xl) * 16 + r] = acc[xl][j];
+                    for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wave + xl) * 16 + r] = acc[xl][j];
             }
             __syncthreads();
             // ---- phase D: the wave's four units -----------------------------------------------------------------------
 #pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
-                const int ml = wave * 4 + u4, m = g * 16 + ml;
+            for (int u4 = 0; u4 < UPW; ++u4) {
+                const int ml = wave * UPW + u4, m = g * 16 + ml;
                 if (m >= 2 * F) continue;
                 const int dh = m >= F ? 1 : 0, i = m - dh * F;
                 (void)dh;
@@ -2121,8 +2122,8 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
     }
     // ---- write this workgroup's part of the slab ------------------------------------------------------------------
 #pragma unroll
-    for (int u4 = 0; u4 < 4; ++u4) {
-        const int m = g * 16 + wave * 4 + u4;
+    for (int u4 = 0; u4 < UPW; ++u4) {
+        const int m = g * 16 + wave * UPW + u4;
         if (m >= 2 * F) continue;
         const int dh = m >= F ? 1 : 0, i = m - dh * F;
         const int nj = F - 1 - i, K2 = 2 * nj, base = i * (2 * F - i - 1) / 2;
@@ -2141,18 +2142,18 @@ __global__ __launch_bounds__(256, 2) void conv0_fact_tile_wgrad_kernel(WgradArgs
     }
     if (g == 0) {
         // rows of padded pairs (p >= P) are never produced: they must read as zeros in the reduction
-        for (int e = tid; e < 4 * (PpT - P) * 16; e += 256) {
+        for (int e = tid; e < 4 * (PpT - P) * 16; e += NTH) {
             const int q = e & 15, rest = e >> 4, p = P + rest % (PpT - P), tap = rest / (PpT - P);
             sw[((int64_t)tap * PpT + p) * PpT + q0 + q] = 0.f;
         }
         __syncthreads();
-        float* red = dTg;                                      // [16 parts][16 q]
+        float* red = dTg;                                      // [NTH/16 parts][16 q]
         red[(tid >> 4) * 16 + (tid & 15)] = bsum;
         __syncthreads();
         if (tid < 16) {
             float v = 0.f;
 #pragma unroll
-            for (int part = 0; part < 16; ++part) v += red[part * 16 + tid];
+            for (int part = 0; part < NTH / 16; ++part) v += red[part * 16 + tid];
             sb[q0 + tid] = v;
         }
     }
@@ -2162,10 +2163,11 @@ static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream
     const int S = a.D / 2, G = (2 * a.F + 15) / 16;
     if (S > 32) return CFFM_ERR_UNSUPPORTED;
     const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 16 * 256) * 4 + 16;
-    int rc = set_lds(conv0_fact_tile_wgrad_kernel<32>, lds);
+    constexpr int NW = 8;
+    int rc = set_lds(conv0_fact_tile_wgrad_kernel<32, NW>, lds);
     if (rc) return rc;
     const int64_t grid = (int64_t)(a.Pp / 16) * G * nslab;
-    hipLaunchKernelGGL((conv0_fact_tile_wgrad_kernel<32>), dim3((unsigned)grid), dim3(256), lds, st, a, nslab);
+    hipLaunchKernelGGL((conv0_fact_tile_wgrad_kernel<32, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, st, a, nslab);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
