@@ -2180,16 +2180,17 @@ static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream
 // dC tile, recomputes the 16 T planes and the 16 dT planes of the group in LDS and feeds two accumulators that live in
 // registers across the walk: dEi of the group (K split over the wavefronts, summed at the end of the group) and dEj
 // (each wavefront sums its own four units, summed at the very end).  ~325 MFLOP per example at F32 D64 against 2,015.
-template <int SMAX>
-__global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a) {
+template <int SMAX, int NW>
+__global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArgs a) {
+    constexpr int NTH = 64 * NW, UPW = 16 / NW, KPW = 64 / NW;   // units / phase-C columns per wavefront, phase-B k-steps per wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, YT = S / 16, PpT = a.Pp, QT = PpT / 16, G = (2 * F + 15) / 16;
     float* Es = reinterpret_cast<float*>(smem);                // [F][Dp]
     float* dCt = Es + (F * Dp + 3) / 4 * 4;                    // [S][16 x][16 q]
     float* Tg = dCt + SMAX * 256;                               // [16 m][16 x][16 q]
     float* dTg = Tg + 4096;                                     // [16 m][16 x][16 q]
-    float* part = dTg + 4096;                                   // [4 waves][4 tiles][64 lanes][4]   cross-wave sums
-    float* dEi = part + 4 * 4 * 256;                            // [G*16][SMAX]    (n = dh*F + i, y)
+    float* part = dTg + 4096;                                   // [NW waves][4 tiles][64 lanes][4]   cross-wave sums
+    float* dEi = part + NW * 4 * 256;                            // [G*16][SMAX]    (n = dh*F + i, y)
     float* dEj = dEi + 64 * SMAX;                               // [64][SMAX]      (n = dw*F + j, x)
     float* rs = dEj + 64 * SMAX;                                // [F] row sums, [F] dots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
@@ -2197,7 +2198,7 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
     {
         const float* e = a.Cprev + (int64_t)b * F * D;
         const float invD = 1.f / (float)D;
-        for (int i = tid; i < F * D; i += 256) {
+        for (int i = tid; i < F * D; i += NTH) {
             const int f = fast_div(i, invD), d = i - f * D;
             Es[f * Dp + d] = e[i];
         }
@@ -2220,7 +2221,7 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
         for (int qt = 0; qt < QT; ++qt) {
             const int q0 = qt * 16;
             __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
-            for (int e4 = tid; e4 < S * 16 * 4; e4 += 256) {   // the dC tile is staged ONCE for the four row groups
+            for (int e4 = tid; e4 < S * 16 * 4; e4 += NTH) {   // the dC tile is staged ONCE for the four row groups
                 const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
                 *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) =
                     *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
@@ -2234,8 +2235,8 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
                 if (g > 0) __syncthreads();                    // Tg / dTg of the previous group consumed
                 // ---- A: T planes of this wave's four units ---------------------------------------------------------
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) {
-                    const int ml = wave * 4 + u4, m = g * 16 + ml;
+                for (int u4 = 0; u4 < UPW; ++u4) {
+                    const int ml = wave * UPW + u4, m = g * 16 + ml;
                     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (m < 2 * F) {
                         const int dh = m >= F ? 1 : 0, i = m - dh * F;
@@ -2259,24 +2260,24 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
                 if (g == 0) __syncthreads();                   // dCt staged
                 // ---- C: dT planes of the group, wave's columns 4*wave .. 4*wave+3 --------------------------------------
                 {
-                    f32x4 acc[4];
+                    f32x4 acc[UPW];
 #pragma unroll
-                    for (int xl = 0; xl < 4; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int xl = 0; xl < UPW; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     for (int s4 = 0; s4 < S / 4; ++s4) {
                         const int y = 4 * s4 + kk;
                         const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
 #pragma unroll
-                        for (int xl = 0; xl < 4; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + 4 * wave + xl) * 16 + r], acc[xl]);
+                        for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + UPW * wave + xl) * 16 + r], acc[xl]);
                     }
 #pragma unroll
-                    for (int xl = 0; xl < 4; ++xl)
+                    for (int xl = 0; xl < UPW; ++xl)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + 4 * wave + xl) * 16 + r] = acc[xl][j];
+                        for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wave + xl) * 16 + r] = acc[xl][j];
                 }
                 __syncthreads();                               // Tg and dTg written
                 // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, 16 per wave), cols m -----------------
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int kf = 4 * (wave * 16 + ks) + kk, x = kf >> 4, q = kf & 15;
+                for (int ks = 0; ks < KPW; ++ks) {
+                    const int kf = 4 * (wave * KPW + ks) + kk, x = kf >> 4, q = kf & 15;
                     const float bv = Tg[(r * 16 + x) * 16 + q];
 #pragma unroll
                     for (int yt = 0; yt < 2; ++yt)
@@ -2284,8 +2285,8 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
                 }
                 // ---- E: dEj rows (dw,j), K = q, cols x: this wave's four units ------------------------------------------
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) {
-                    const int ml = wave * 4 + u4, m = g * 16 + ml;
+                for (int u4 = 0; u4 < UPW; ++u4) {
+                    const int ml = wave * UPW + u4, m = g * 16 + ml;
                     if (m >= 2 * F) continue;
                     const int dh = m >= F ? 1 : 0, i = m - dh * F, base = i * (2 * F - i - 1) / 2;
                     const float4 bv = *reinterpret_cast<const float4*>(dTg + (ml * 16 + r) * 16 + 4 * kk);   // [k = q = 4kk+t][n = x = r]
@@ -2317,11 +2318,11 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
         for (int yt = 0; yt < 2; ++yt)
             *reinterpret_cast<f32x4*>(part + ((wave * 4 + yt) * 64 + lane) * 4) = accB[g][yt];
         __syncthreads();
-        for (int e = tid; e < YT * 256; e += 256) {              // e = (yt, lane, j)
+        for (int e = tid; e < YT * 256; e += NTH) {              // e = (yt, lane, j)
             const int j = e & 3, ln = (e >> 2) & 63, yt = e >> 8;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += part[((w * 4 + yt) * 64 + ln) * 4 + j];
+            for (int w = 0; w < NW; ++w) v += part[((w * 4 + yt) * 64 + ln) * 4 + j];
             const int y = yt * 16 + (ln >> 4) * 4 + j, mm = g * 16 + (ln & 15);          // D layout: row y, col m
             dEi[mm * SMAX + y] = v;
         }
@@ -2334,11 +2335,11 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part + ((wave * 4 + t) * 64 + lane) * 4) = accE[xt][t];
         __syncthreads();
-        for (int e = tid; e < 4 * 256; e += 256) {              // e = (t, lane, j)
+        for (int e = tid; e < 4 * 256; e += NTH) {              // e = (t, lane, j)
             const int j = e & 3, ln = (e >> 2) & 63, t = e >> 8;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += part[((w * 4 + t) * 64 + ln) * 4 + j];
+            for (int w = 0; w < NW; ++w) v += part[((w * 4 + t) * 64 + ln) * 4 + j];
             const int n = t * 16 + (ln >> 4) * 4 + j, x = xt * 16 + (ln & 15);           // D layout: row (dw,j), col x
             dEj[n * SMAX + x] = v;
         }
@@ -2351,7 +2352,7 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
         rs[tid] = sacc;
     }
     __syncthreads();
-    for (int e = tid; e < F * D; e += 256) {
+    for (int e = tid; e < F * D; e += NTH) {
         const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
         float R = 0.f, Q = 0.f;
         for (int j = f + 1; j < F; ++j) R += rs[j];
@@ -2364,10 +2365,11 @@ __global__ __launch_bounds__(256) void conv0_fact_tile_dgrad_kernel(DgradArgs a)
 static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
     const int S = a.D / 2;
     if (S > 32 || 2 * a.F > 64) return CFFM_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 4096 + 4096 + 4 * 4 * 256 + 64 * 32 + 64 * 32 + 2 * a.F) * 4 + 16;
-    int rc = set_lds(conv0_fact_tile_dgrad_kernel<32>, lds);
+    constexpr int NW = 4;                // measured at F32 D64 B8192: 118 ms with 4 wavefronts, 194 ms with 8 (register spills)
+    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 4096 + 4096 + NW * 4 * 256 + 64 * 32 + 64 * 32 + 2 * a.F) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_dgrad_kernel<32, NW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((conv0_fact_tile_dgrad_kernel<32>), dim3(a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv0_fact_tile_dgrad_kernel<32, NW>), dim3(a.B), dim3(64 * NW), lds, st, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
