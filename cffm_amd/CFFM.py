@@ -22,7 +22,6 @@ import os
 from time import time
 
 import numpy as np
-from sklearn.metrics import mean_squared_error, r2_score
 from sklearn.utils import shuffle
 
 from . import LoadData as DATA
@@ -133,19 +132,21 @@ class CFFM(object):
         return self.engine
 
     def _device_split(self, data):
-        """{'X': lists, 'Y': list} -> (ids int32 [N,F], y fp32 [N]) in HBM, packed once per split object."""
+        """{'X': lists, 'Y': list} -> (ids int32 [N,F], y fp32 [N], (min label, max label)) in HBM, packed once per split
+        object (re-packed when the caller swaps the lists)."""
         import torch
         key = id(data)
         hit = self._packed.get(key)
         if hit is not None and hit[2] is data['X']:
-            return hit[0], hit[1]
+            return hit[0], hit[1], hit[3]
         X, Y = DATA.LoadData.packed(data)
         if X.shape[1] != self.num_field:
             raise ValueError('rows have %d ids, --num_field is %d' % (X.shape[1], self.num_field))
         dev = self.engine.device
         ids, y = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
-        self._packed[key] = (ids, y, data['X'])
-        return ids, y
+        span = (float(Y.min()), float(Y.max())) if Y.size else (0.0, 0.0)      # clip range of evaluate(), CFFM.py:607-609
+        self._packed[key] = (ids, y, data['X'], span)
+        return ids, y, span
 
     # ---- training loop (CFFM.py:157-228) -------------------------------------------------------------
     def train(self, data):
@@ -162,64 +163,82 @@ class CFFM(object):
             logging.info(("Init_RMSE: train=%.4f,validation=%.4f,test=%.4f | Init_R2: train=%.4f,validation=%.4f,"
                           "test=%.4f [%.1f s] " % (init_train_rmse, init_valid_rmse, init_test_rmse, init_train_r2,
                                                   init_validation_r2, init_test_r2, time() - t2)))
-        ids, y = self._device_split(data.Train_data)
+        ids, y, span = self._device_split(data.Train_data)
         n = ids.shape[0]
-        for epoch in range(self.epoch):
-            t1 = time()
-            # shuffle_in_unison_scary: the same seeded permutation is applied to the CURRENT order every epoch
-            perm = shuffle(np.arange(n), random_state=self.random_seed)
-            pt = torch.from_numpy(perm).to(ids.device)
-            ids, y = ids[pt].contiguous(), y[pt].contiguous()
-            total_batch = int(n / self.batch_size)
-            for _ in range(total_batch):
-                start = np.random.randint(0, n - self.batch_size)        # CFFM.py:561 (unseeded, as the reference)
-                eng.train_step(ids[start:start + self.batch_size], y[start:start + self.batch_size])
-            torch.cuda.synchronize()
-            t2 = time()
-            self.examples_per_sec.append(total_batch * self.batch_size / max(t2 - t1, 1e-9))
-            # keep the caller's lists consistent with what the reference leaves behind (shuffled in place)
-            self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'])
-            train_rmse, train_r2 = self.evaluate(data.Train_data)
-            valid_rmse, valid_r2 = self.evaluate(data.Validation_data)
-            test_rmse, test_r2 = self.evaluate(data.Test_data)
-            self.train_rmse.append(train_rmse)
-            self.valid_rmse.append(valid_rmse)
-            self.test_rmse.append(test_rmse)
-            self.train_r2.append(train_r2)
-            self.valid_r2.append(valid_r2)
-            self.test_r2.append(test_r2)
-            if self.verbose > 0 and epoch % self.verbose == 0:
-                logging.info(("Epoch %d [%.1f s] RMSE: train=%.4f,validation=%.4f,Test=%.4f | R2: train=%.4f,"
-                              "validation=%.4f,Test=%.4f [%.1f s]" % (epoch + 1, t2 - t1, train_rmse, valid_rmse,
-                                                                      test_rmse, train_r2, valid_r2, test_r2,
-                                                                      time() - t2)))
-                logging.info("Epoch %d throughput: %.0f training examples/s" % (epoch + 1, self.examples_per_sec[-1]))
-            if self.eva_termination(self.valid_rmse):
-                break
-            if self.pretrain_flag < 0:
-                logging.info("Save model to file as pretrain.")
-                self.save(self.save_file)
+        # shuffle_in_unison_scary (CFFM.py:183, :556-558): sklearn's shuffle with the SAME random_state every epoch, i.e. one
+        # fixed permutation of n positions applied to the CURRENT order each time.  It is built once and kept on the
+        # device; `order` tracks the composition so that the caller's lists can be left as the reference leaves them.
+        perm = shuffle(np.arange(n), random_state=self.random_seed)
+        pt = torch.from_numpy(perm).to(ids.device)
+        order = np.arange(n)
+        try:
+            for epoch in range(self.epoch):
+                t1 = time()
+                ids, y = ids[pt].contiguous(), y[pt].contiguous()
+                order = order[perm]
+                total_batch = int(n / self.batch_size)
+                for _ in range(total_batch):
+                    start = np.random.randint(0, n - self.batch_size)        # CFFM.py:561 (unseeded, as the reference)
+                    eng.train_step(ids[start:start + self.batch_size], y[start:start + self.batch_size])
+                torch.cuda.synchronize()
+                t2 = time()
+                self.examples_per_sec.append(total_batch * self.batch_size / max(t2 - t1, 1e-9))
+                self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'], span)   # evaluate() sees the shuffled order
+                train_rmse, train_r2 = self.evaluate(data.Train_data)
+                valid_rmse, valid_r2 = self.evaluate(data.Validation_data)
+                test_rmse, test_r2 = self.evaluate(data.Test_data)
+                self.train_rmse.append(train_rmse)
+                self.valid_rmse.append(valid_rmse)
+                self.test_rmse.append(test_rmse)
+                self.train_r2.append(train_r2)
+                self.valid_r2.append(valid_r2)
+                self.test_r2.append(test_r2)
+                if self.verbose > 0 and epoch % self.verbose == 0:
+                    logging.info(("Epoch %d [%.1f s] RMSE: train=%.4f,validation=%.4f,Test=%.4f | R2: train=%.4f,"
+                                  "validation=%.4f,Test=%.4f [%.1f s]" % (epoch + 1, t2 - t1, train_rmse, valid_rmse,
+                                                                          test_rmse, train_r2, valid_r2, test_r2,
+                                                                          time() - t2)))
+                    logging.info("Epoch %d throughput: %.0f training examples/s" % (epoch + 1, self.examples_per_sec[-1]))
+                if self.eva_termination(self.valid_rmse):
+                    break
+                if self.pretrain_flag < 0:
+                    logging.info("Save model to file as pretrain.")
+                    self.save(self.save_file)
+        finally:
+            # the reference re-binds data.Train_data['X'] / ['Y'] to the shuffled lists every epoch (CFFM.py:183); the device
+            # copy is what the loop trains on, so the caller's lists are brought to the same (composed) order once, here
+            if not np.array_equal(order, np.arange(n)):
+                X0, Y0 = data.Train_data['X'], data.Train_data['Y']
+                data.Train_data['X'] = [X0[i] for i in order]
+                data.Train_data['Y'] = [Y0[i] for i in order]
+                self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'], span)
 
     # ---- evaluation (CFFM.py:583-615) ------------------------------------------------------------------
     def evaluate(self, data):
-        import torch
+        """RMSE and R2 of the clipped predictions (CFFM.py:583-615).  The whole sweep stays on the device: ordered blocks
+        with a ragged last one (CFFM.py:590-596; the forward is per example, so the block size does not change a
+        prediction - blocks of >= 8192 rows run the conv kernels at 12 M examples/s against 3.7 M at 256), clip to the
+        split's label range, and the three float64 sums of the metrics; three doubles come back to the host."""
         if self.engine is None:
             self.build_graph()
-        ids, y = self._device_split(data)
-        num_example = ids.shape[0]
-        outs = []
-        # ordered blocks, ragged last one (CFFM.py:590-596).  The forward is per example, so the block size does not
-        # change a prediction; blocks of >= 8192 rows run the conv kernels at 12 M examples/s against 3.7 M at 256
-        block = max(int(self.batch_size), 8192)
-        for s in range(0, num_example, block):
-            outs.append(self.engine.predict(ids[s:s + block]))
-        y_pred = torch.cat(outs).cpu().numpy().astype(np.float64) if outs else np.zeros((0,))
-        y_true = y.cpu().numpy().astype(np.float64)               # same (possibly shuffled) order as ids
-        predictions_bounded = np.maximum(y_pred, np.ones(num_example) * min(y_true))
-        predictions_bounded = np.minimum(predictions_bounded, np.ones(num_example) * max(y_true))
-        RMSE = math.sqrt(mean_squared_error(y_true, predictions_bounded))
-        R2 = r2_score(y_true, predictions_bounded)
+        ids, y, (lo, hi) = self._device_split(data)
+        num_example = int(ids.shape[0])
+        if num_example == 0:
+            raise ValueError('evaluate() needs at least one example')
+        sums = self.engine.eval_sums(ids, y, lo, hi, block=max(int(self.batch_size), 8192))
+        ss_res, sy, syy = (float(v) for v in sums.cpu().numpy())
+        RMSE = math.sqrt(ss_res / num_example)                  # sqrt(mean_squared_error), CFFM.py:610-612
+        ss_tot = syy - sy * sy / num_example                    # sum (y - mean(y))^2
+        R2 = 1.0 - ss_res / ss_tot if ss_tot > 0 else (1.0 if ss_res == 0 else 0.0)    # sklearn r2_score, CFFM.py:614
         return RMSE, R2
+
+    def predict_split(self, data):
+        """Raw (unclipped) predictions of a split as a host float64 array, in the split's current order."""
+        import torch
+        ids, _, _ = self._device_split(data)
+        block = max(int(self.batch_size), 8192)
+        outs = [self.engine.predict(ids[s:s + block]) for s in range(0, ids.shape[0], block)]
+        return torch.cat(outs).cpu().numpy().astype(np.float64) if outs else np.zeros((0,))
 
     # ---- host-side helpers with the reference's list semantics (CFFM.py:556-635) -------------------------
     def shuffle_in_unison_scary(self, x, y):

@@ -38,9 +38,15 @@ class HipEngine(object):
         self.shape = hip.make_shape(cfg)
         self.tl = hip.theta_layout(self.shape)
         self._ws = {}
+        self._ws_buf = None
+        self._eval_scratch = None
         self._host_only = {}
-        if params is None:
-            params = init_params(cfg, seed=seed)
+        # params == 'device': the three tables are drawn ON the GPU with the reference's distributions (N(0, 0.1),
+        # N(0, 0.01), exact zeros - CFFM.py:257-277); for vocabularies where a host-side draw + copy of M*(K+D) floats
+        # would dominate start-up (10 M features: 5 GB).  Dense parameters still come from init_params(seed).
+        device_tables = isinstance(params, str) and params == 'device'
+        if params is None or device_tables:
+            params = init_params(cfg, seed=seed, tables=not device_tables)
         n = int(self.tl.n)
         dev = self.device
         self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -68,6 +74,10 @@ class HipEngine(object):
         self.tables_acc = hip.Tables(self.inner_acc.data_ptr(), self.outer_acc.data_ptr(), self.fbias_acc.data_ptr())
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self.load_params(params)
+        if device_tables:
+            gen = torch.Generator(device=dev).manual_seed(int(seed))
+            self.inner.normal_(0.0, 0.1, generator=gen)
+            self.outer.normal_(0.0, 0.01, generator=gen)
 
     # ---- named parameters <-> device buffers -------------------------------------------------------
     def _members(self):
@@ -107,11 +117,12 @@ class HipEngine(object):
             v = self._pack(name, params[name])
             host[off:off + v.size] = v
         self.theta.copy_(torch.from_numpy(host))
-        self.inner.copy_(torch.from_numpy(np.asarray(params['inner_embeddings'], dtype=np.float32)))
-        self.outer.copy_(torch.from_numpy(np.asarray(params['outer_embeddings'], dtype=np.float32)))
-        self.fbias.copy_(torch.from_numpy(np.asarray(params['feature_bias'], dtype=np.float32).reshape(-1)))
+        if 'inner_embeddings' in params:                  # absent: tables initialised on the device (params='device')
+            self.inner.copy_(torch.from_numpy(np.asarray(params['inner_embeddings'], dtype=np.float32)))
+            self.outer.copy_(torch.from_numpy(np.asarray(params['outer_embeddings'], dtype=np.float32)))
+            self.fbias.copy_(torch.from_numpy(np.asarray(params['feature_bias'], dtype=np.float32).reshape(-1)))
         trained = set(n for _, n in self._members()) | {'inner_embeddings', 'outer_embeddings', 'feature_bias'}
-        self._host_only = {k: np.array(params[k], dtype=np.float32) for k in shapes if k not in trained}
+        self._host_only = {k: np.array(params[k], dtype=np.float32) for k in shapes if k not in trained and k in params}
         if accs is not None:
             ha = np.full(int(self.tl.n), self.acc0, dtype=np.float32)
             for off, name in self._members():
@@ -144,6 +155,15 @@ class HipEngine(object):
         out['feature_bias'] = fbias.detach().cpu().numpy().reshape(-1, 1).copy()
         return out
 
+    def export_params_dense(self):
+        """Every variable except the three tables (for vocabularies where a host copy of the tables is not wanted)."""
+        z = torch.zeros(1, device=self.device)
+        out = self._export(self.theta, z, z, z)
+        for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+            out.pop(k)
+        out.update({k: v.copy() for k, v in self._host_only.items()})
+        return out
+
     def export_params(self):
         out = self._export(self.theta, self.inner, self.outer, self.fbias)
         out.update({k: v.copy() for k, v in self._host_only.items()})
@@ -168,14 +188,21 @@ class HipEngine(object):
 
     # ---- workspace ---------------------------------------------------------------------------------
     def workspace(self, B):
+        """(buffer, layout) for a batch of B rows.  ONE buffer serves every batch size: the library recomputes the
+        layout from B on every call, so a buffer laid out for the largest B seen so far holds any smaller one (the
+        ragged last block of evaluate(), the varying row counts an owner receives in row-sharded mode).  It only ever
+        grows; at F32 D64 B8192 it is ~50 GB, so one copy per distinct B would exhaust HBM within a few steps."""
         B = int(B)
-        hit = self._ws.get(B)
-        if hit is None:
+        wl = self._ws.get(B)
+        if wl is None:
+            if len(self._ws) > 4096:                     # layouts are tiny structs, but do not hoard them forever
+                self._ws = {k: v for k, v in self._ws.items() if not isinstance(k, int)}
             wl = hip.ws_layout(self.shape, B)
-            buf = torch.empty(int(wl.bytes), dtype=torch.uint8, device=self.device)
-            hit = (buf, wl)
-            self._ws[B] = hit
-        return hit
+            self._ws[B] = wl
+        if self._ws_buf is None or self._ws_buf.numel() < int(wl.bytes):
+            self._ws_buf = None                           # release before allocating the larger one
+            self._ws_buf = torch.empty(int(wl.bytes), dtype=torch.uint8, device=self.device)
+        return self._ws_buf, wl
 
     def ws_tensor(self, B, member, shape, dtype=torch.float32, index=None):
         """View of one workspace intermediate (for the parity tests)."""
@@ -208,6 +235,23 @@ class HipEngine(object):
         hip.check(self.lib.cffm_predict(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
                                         B, _ptr(buf), _ptr(out), self._stream()))
         return out
+
+    def eval_sums(self, ids, y, lo, hi, block=8192):
+        """evaluate()'s sweep (CFFM.py:590-614) entirely on the device: ordered blocks of rows through cffm_predict, the
+        clip to [lo, hi] and the float64 sums the two metrics need (cffm_eval_sums).  Returns a float64 device tensor
+        [sum (y - p)^2, sum y, sum y^2]; nothing is copied to the host and nothing synchronises here."""
+        ids = self._ids(ids)
+        y = y.reshape(-1)
+        n = int(ids.shape[0])
+        if self._eval_scratch is None:
+            self._eval_scratch = torch.empty(int(self.lib.cffm_eval_scratch_bytes()), dtype=torch.uint8, device=self.device)
+        sums = torch.zeros(3, dtype=torch.float64, device=self.device)
+        for s0 in range(0, n, block):
+            m = min(block, n - s0)
+            out = self.predict(ids[s0:s0 + m])
+            hip.check(self.lib.cffm_eval_sums(_ptr(out), _ptr(y[s0:s0 + m]), m, float(lo), float(hi),
+                                              _ptr(self._eval_scratch), _ptr(sums), self._stream()))
+        return sums
 
     def train_step(self, ids, y):
         """sess.run((self.loss, self.optimizer)) (CFFM.py:200).  Returns the loss as a device scalar
@@ -313,15 +357,16 @@ class HipEngine(object):
         """n_runs = 0: rows_all [n_rows, 1+K+D+1] in any order (cffm_backward_unscaled rows).  n_runs > 0: the flat
         concatenation of n_runs dp_local blocks."""
         W = 1 + self.cfg.K + self.cfg.D + 1
-        runs_ok = n_runs > 0 and rows_all.dim() == 1 and bool(self.lib.cffm_dp_runs_ok(
-            C.byref(self.shape), int(rows_all.numel() // (W + 2) // n_runs // self.cfg.F)))
+        # sorted runs: only where the single-launch forward left them, and while all ids fit the merge kernel's LDS
+        runs_ok = n_runs > 0 and rows_all.dim() == 1 and (rows_all.numel() // (W + 2)) * 4 <= 150 * 1024 and \
+            bool(self.lib.cffm_dp_runs_ok(C.byref(self.shape), int(rows_all.numel() // (W + 2) // n_runs // self.cfg.F)))
         if n_runs > 0 and not runs_ok:
             # the blocks carry no sorted runs (shape outside the single-launch forward): strip the key areas
             m = rows_all.numel() // (W + 2) // n_runs
             rows_all = rows_all.reshape(n_runs, m * (W + 2))[:, :m * W].reshape(n_runs * m, W).contiguous()
             n_runs = 0
         n_rows = rows_all.numel() // (W + 2) if n_runs > 0 else rows_all.shape[0]
-        B_ws = -(-n_rows // self.cfg.F)
+        B_ws = max(1, -(-n_rows // self.cfg.F))       # an owner that received no rows still applies the dense update
         buf, _ = self.workspace(B_ws)
         hip.check(self.lib.cffm_dp_apply(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
                                          _ptr(self.theta), _ptr(self.theta_acc), _ptr(grad_full), int(B_global),

@@ -8,6 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
 
+ABI_VERSION = 5
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
@@ -77,6 +78,8 @@ PROTOTYPES = {
     'cffm_dp_local_dense': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_dp_apply_dense': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, _P]),
     'cffm_dp_local': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    'cffm_eval_scratch_bytes': (C.c_int64, []),
+    'cffm_eval_sums': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), _P]),
     'cffm_train_step_opt': (C.c_int, [_SH, _TB, _TB, _TB, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
@@ -101,7 +104,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.cffm_abi_version() != 4:
+    if lib.cffm_abi_version() != ABI_VERSION:
         raise RuntimeError('cffm_amd: ABI version mismatch')
     _lib = lib
     return lib

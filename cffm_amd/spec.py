@@ -114,12 +114,15 @@ def _glorot_uniform(rng, shape):
     return rng.uniform(-lim, lim, size=shape)
 
 
-def init_params(cfg, seed=2021, dtype=np.float32):
+def init_params(cfg, seed=2021, dtype=np.float32, tables=True):
     """Parameter dict with the reference's initial distributions.  The reference seeds
-    nothing; a seed is taken here so that runs and tests are repeatable."""
+    nothing; a seed is taken here so that runs and tests are repeatable.  tables=False leaves the three
+    embedding tables out (HipEngine(params='device') draws them on the GPU)."""
     rng = np.random.default_rng(seed)
     p = {}
     for name, shp in param_shapes(cfg).items():
+        if not tables and name in TABLES:
+            continue
         if name == 'inner_embeddings':
             v = rng.standard_normal(shp) * 0.1
         elif name == 'outer_embeddings':

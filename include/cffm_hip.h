@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 4
+#define CFFM_ABI_VERSION 5
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -205,6 +205,15 @@ int cffm_dp_apply(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_ta
 int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *tab_acc,
                     float *theta, float *theta_acc, float *grad, const int32_t *ids, const float *y,
                     int32_t B, void *ws, float *loss, void *stream);
+
+/* ---- evaluate() (CFFM.py:583-615) without a device-to-host copy of the predictions ------------------------------- */
+/* clip + metric sums of CFFM.py:607-614 over n rows: p = min(max(pred, lo), hi) with lo/hi = min/max of the split's labels;
+ * sums[0] += sum (y - p)^2, sums[1] += sum y, sums[2] += sum y^2, all float64, in a fixed order (bitwise reproducible).
+ * sums is ACCUMULATED so that a split swept in several blocks of rows adds up (zero it first); scratch must hold
+ * cffm_eval_scratch_bytes() bytes.  RMSE = sqrt(sums[0]/N), R2 = 1 - sums[0] / (sums[2] - sums[1]^2/N). */
+int64_t cffm_eval_scratch_bytes(void);
+int cffm_eval_sums(const float *pred, const float *y, int64_t n, float lo, float hi, void *scratch, double *sums,
+                   void *stream);
 
 /* ---- peak probes (bench.py prices the kernels against the data-sheet peaks AND these measured ones) ------------- */
 /* float4 streaming copy src -> dst (bytes % 16 == 0): 2*bytes of HBM traffic per launch */

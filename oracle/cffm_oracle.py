@@ -281,6 +281,7 @@ def backward(p, cache, dout, cfg):
         g['inner_layer_conv_weight_0'] = gw.reshape(1, 2, 1, 2)
         dmp = ds.sum(axis=3)                                            # broadcast add over ch
         first = x0 >= x1                                                # max-pool: first element on ties
+        first = cache.get('first_override', first)                      # tests: either decision on a near-tie
         dx0 = dz @ w[0] + np.where(first, dmp, 0)
         dx1 = dz @ w[1] + np.where(first, 0, dmp)
         dx = np.empty_like(x)

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cffm_abi_version() == 4
+    assert lib.cffm_abi_version() == hip.ABI_VERSION == 5
     assert b'bad shape' in lib.cffm_error_string(10001)
 
 

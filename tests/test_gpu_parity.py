@@ -1,6 +1,6 @@
 """GPU parity: every stage of the HIP path, called through the C ABI, against the float64 oracle on
-the same seeded inputs.  Tolerance is the north-star one (1e-5 relative fp32), applied per tensor as
-|got - ref| <= 1e-5 * max(|ref| element, max|ref| of the tensor)."""
+the same seeded inputs.  Tolerance is the north-star one (1e-5 relative fp32), applied element-wise against
+1e-5 * (|ref| + rms(ref)) in the three tiers close() documents."""
 import numpy as np
 import pytest
 import torch
@@ -11,22 +11,54 @@ from oracle import cffm_oracle as orc
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+REL_FLOOR = 1e-3          # elements above REL_FLOOR * max|ref| must also be within REL_TOL relative (an fp32 sum carries
+                          # ~1e-7 * max of absolute rounding error, i.e. 1e-3 relative on an element of 1e-4 * max)
+REL_TOL = 1e-3
+WORST = {}                # name -> worst (|err| / bound) seen, printed at the end of the session (see conftest)
 
 
 def close(got, ref, name, tol=TOL, ignore=None, extra=None):
+    """Element-wise, genuinely relative bound  B = tol * (|ref| + rms(ref)) [+ extra]:
+
+      tier 1   at least 99 % of the elements within B
+      tier 2   EVERY element within 4 * B
+      tier 3   every element above 1e-3 * max|ref| within 1e-3 relative
+
+    An fp32 sum of n terms carries an absolute error that scales with the magnitude of its terms, i.e. with the typical
+    size of the tensor (its rms), not with the element itself - hence |ref| + rms, NOT tol * max|ref| (which would let
+    an element 1000x below the maximum be 1 % wrong).  Rounding error is statistical: a value that went through ~10
+    chained fp32 contractions (forward conv stack, head, backward stack) typically sits at 2-5e-6 of that scale and the
+    worst of a million elements at ~1e-5 (numpy's own fp32 evaluation of the oracle lands at 1.2-2.1e-5 * rms on the
+    ill-conditioned outputs of 'f20-d32-b300-selu'), hence the two tiers instead of one loosened tolerance.  ``extra``
+    adds a bound propagated from an upstream tolerance (optimizer amplification, dL/dout cancellation; see the callers).
+    The worst err / B per tensor is recorded in WORST and written to gpurun_out/parity_worst.json."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    scale = max(float(np.abs(ref).max()), 1e-30)
+    if ref.size == 0:
+        return
+    amax = max(float(np.abs(ref).max()), 1e-30)
+    rms = max(float(np.sqrt(np.mean(ref * ref))), 1e-30)
     err = np.abs(got - ref)
-    bound = tol * np.maximum(np.abs(ref), scale)
+    bound = tol * (np.abs(ref) + rms)
     if extra is not None:
         bound = bound + extra
-    bad = err > bound
+    big = np.abs(ref) >= REL_FLOOR * amax
+    rel_bound = REL_TOL * np.abs(ref) + (extra if extra is not None else 0.0)
+    over1 = err > bound
+    bad = (err > 4.0 * bound) | (big & (err > rel_bound))
     if ignore is not None:
+        over1 &= ~ignore
         bad &= ~ignore
-    assert not bad.any(), '%s: %d/%d beyond tol, max err %.3e (tensor scale %.3e) at %s' % (
-        name, int(bad.sum()), bad.size, float(err.max()), scale, np.unravel_index(int(err.argmax()), err.shape))
+    allowed = int(np.ceil(0.01 * ref.size)) if ref.size > 1 else 0
+    ratio = float((err / bound).max())
+    WORST[name] = max(WORST.get(name, 0.0), ratio)
+    rel_big = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
+    assert not bad.any() and int(over1.sum()) <= allowed, \
+        '%s: %d/%d beyond tol (%d allowed), %d beyond the hard bound, max err %.3e (rms %.3e, max %.3e), worst err/bound ' \
+        '%.2f, worst rel err above floor %.2e at %s' % (name, int(over1.sum()), bad.size, allowed, int(bad.sum()),
+                                                       float(err.max()), rms, amax, ratio, rel_big,
+                                                       np.unravel_index(int((err / bound).argmax()), err.shape))
 
 
 CASES = {
@@ -45,20 +77,41 @@ CASES = {
     # input-gradient kernel falls back to the direct contraction
     'f20-d64-elu': dict(M=2000, F=20, K=16, D=64, act='elu', B=2),
     'f33-d32-relu': dict(M=3000, F=33, K=8, D=32, act='relu', B=2),
+    # wide filters with SEVERAL examples per gradient slab (the tiled layer-0 weight gradient walks b = slab, slab + 64, ...)
+    # and the direct kernels of layers >= 1 at a realistic row count
+    'f16-d32-b130': dict(M=3000, F=16, K=8, D=32, act='relu', B=130),
+    'f20-d32-b300-selu': dict(M=5000, F=20, K=16, D=32, act='selu', B=300),
+    'f32-d64-b160': dict(M=20000, F=32, K=64, D=64, act='relu', B=160, heavy=True),
+    # more than 4,096 lookups per step: the rocPRIM radix sort + segment walk of the sparse update (the CLI's default
+    # --batch_size 1024), with heavy duplication (ids drawn from 150 values per column)
+    'frappe-b1024-dups': dict(M=5382, F=10, K=32, D=32, act='selu', B=1024, id_range=150),
+    'bookx-b1024-dups': dict(M=226336, F=6, K=32, D=32, act='relu', B=1024, id_range=150),
+    # disabled branches (CFFM.py:301, :348), with and without the attention first-order term
+    'no-inner': dict(M=700, F=6, K=32, D=32, act='elu', B=33, inner_conv=0),
+    'no-outer': dict(M=700, F=6, K=32, D=32, act='selu', B=33, outer_conv=0),
+    'no-inner-no-outer': dict(M=700, F=6, K=32, D=32, act='relu', B=33, inner_conv=0, outer_conv=0),
+    'no-inner-nolinatt': dict(M=700, F=10, K=32, D=32, act='relu', B=40, inner_conv=0, linear_att=0),
+    'no-outer-nolinatt': dict(M=700, F=10, K=32, D=32, act='gelu', B=40, outer_conv=0, linear_att=0),
+    'fm-only-nolinatt': dict(M=700, F=5, K=8, D=8, act='relu', B=300, inner_conv=0, outer_conv=0, linear_att=0),
 }
+HEAVY = [k for k, v in CASES.items() if v.get('heavy')]       # oracle needs several GB and ~a minute per pass
+LIGHT = [k for k in CASES if k not in HEAVY]
 
 
 def make_case(name, seed=0, trained_like=True):
     c = CASES[name]
     cfg = CFFMConfig(M=c['M'], F=c['F'], K=c['K'], D=c['D'], activation=c['act'], lamda_att=1.3,
-                     linear_att=c.get('linear_att', 1), loss_type=c.get('loss', 'square_loss'))
+                     linear_att=c.get('linear_att', 1), loss_type=c.get('loss', 'square_loss'),
+                     inner_conv=c.get('inner_conv', 1), outer_conv=c.get('outer_conv', 1))
     p32 = init_params(cfg, seed=seed, dtype=np.float32)
     rng = np.random.default_rng(seed + 7)
     if trained_like:   # feature_bias is exactly 0 at init (CFFM.py:276): make the first-order term non-trivial
         p32['feature_bias'] = (rng.standard_normal(p32['feature_bias'].shape) * 0.3).astype(np.float32)
         p32['outer_embeddings'] = (p32['outer_embeddings'] * 20.0).astype(np.float32)
         p32['inner_embeddings'] = (p32['inner_embeddings'] * 4.0).astype(np.float32)
-    X = rng.integers(0, cfg.M, size=(c['B'], cfg.F)).astype(np.int32)
+    X = rng.integers(0, c.get('id_range', cfg.M), size=(c['B'], cfg.F)).astype(np.int32)
+    if 'id_range' in c:                                # spread the few values over the table (rows far apart)
+        X = (X.astype(np.int64) * (cfg.M // c['id_range'])).astype(np.int32)
     X[0, 0] = X[-1, 0]
     if c['B'] > 2:
         X[1] = X[0]                                   # a fully duplicated row: duplicate ids in every column
@@ -118,7 +171,50 @@ def pad_channels(a, Pp):
     return out
 
 
-@pytest.mark.parametrize('name', list(CASES))
+def inner_kink_slack(p64, cache, dout, cfg):
+    """The inner branch (CFFM.py:327-332) has two discontinuous gradients: relu'(z) of the 1x2 conv at z = 0 and the
+    arg-max of the 2-wide max-pool on a tie.  Its intermediates are never written to memory by the HIP path (one pass
+    in LDS), so the device's decision cannot be read back as adopt_device_kinks does for the conv stack.  Where the
+    float64 value sits within fp32 rounding of the discontinuity (|z| < 1e-5 max|z|, |x0 - x1| < 1e-6 max|x|), BOTH
+    decisions are correct fp32 answers: the slack returned here is |gradient(decision A) - gradient(decision B)| per
+    element, added to the bound of the three gradients that depend on it.  Empty when no element is that close."""
+    if not cfg.inner_conv:
+        return {}
+    import copy
+    z, x = cache['z'], cache['x']
+    kink = np.abs(z) < 1e-5 * np.abs(z).max()
+    x0, x1 = x[:, :, 0::2], x[:, :, 1::2]
+    tie = (np.abs(x0 - x1) < 1e-6 * np.abs(x).max()) & (x0 != x1)
+    if not kink.any() and not tie.any():
+        return {}
+    icfg = copy.copy(cfg)
+    icfg.outer_conv = 0
+    sides = []
+    for side in (0, 1):
+        c2 = dict(cache)
+        r = cache['r'].copy()
+        r[kink] = 0.0 if side == 0 else 1e-30
+        first = x0 >= x1
+        first[tie] = bool(side)
+        c2['r'], c2['first_override'] = r, first
+        sides.append(orc.backward(p64, c2, dout, icfg))
+    print('inner branch: %d relu kinks, %d max-pool near-ties -> two-sided slack' % (int(kink.sum()), int(tie.sum())))
+    return {k: np.abs(np.asarray(sides[0][k]) - np.asarray(sides[1][k]))
+            for k in ('inner_layer_conv_weight_0', 'inner_layer_conv_bias_0', 'd_inner_rows')}
+
+
+def dout_slack(out_ref, y, cfg, p64):
+    """dL/dout is computed from the device's own `out`, which is held to 1e-5 * (|out| + rms): where out ~ y the
+    difference out - y cancels, so the bound on dout is that output tolerance propagated through the loss."""
+    d = TOL * (np.abs(out_ref) + float(np.sqrt(np.mean(out_ref * out_ref))))
+    y64 = y.astype(np.float64)
+    _, g0 = orc.loss_and_grad(out_ref, y64, cfg, p64)
+    _, g1 = orc.loss_and_grad(out_ref + d, y64, cfg, p64)
+    _, g2 = orc.loss_and_grad(out_ref - d, y64, cfg, p64)
+    return np.maximum(np.abs(g1 - g0), np.abs(g2 - g0))
+
+
+@pytest.mark.parametrize('name', LIGHT)
 def test_forward_stages(name):
     cfg, p32, X, y = make_case(name)
     eng = engine_for(cfg, p32)
@@ -129,16 +225,18 @@ def test_forward_stages(name):
     eng.forward(ids, yt)
     torch.cuda.synchronize()
     Pp = eng.tl.Pp
-    np.testing.assert_array_equal(eng.ws_tensor(B, 'Ei', (B, cfg.F, cfg.K)).cpu().numpy(), p32['inner_embeddings'][X])
-    np.testing.assert_array_equal(eng.ws_tensor(B, 'Eo', (B, cfg.F, cfg.D)).cpu().numpy(), p32['outer_embeddings'][X])
+    if cfg.inner_conv:
+        np.testing.assert_array_equal(eng.ws_tensor(B, 'Ei', (B, cfg.F, cfg.K)).cpu().numpy(), p32['inner_embeddings'][X])
+        close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out')
     np.testing.assert_array_equal(eng.ws_tensor(B, 'fb', (B, cfg.F)).cpu().numpy(), p32['feature_bias'][X][:, :, 0])
-    close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out')
-    for l in range(cfg.live_layers):
-        S = cfg.D >> (l + 1)
-        got = eng.ws_tensor(B, 'C', (B, S, S, Pp), index=l).cpu().numpy()
-        close(got, pad_channels(c['rs'][l], Pp), 'C[%d]' % l)
-    close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy(), c['t1'], 't1')
-    close(eng.ws_tensor(B, 'h1', (B, 32)).cpu().numpy(), c['h1'], 'h1')
+    if cfg.outer_conv:
+        np.testing.assert_array_equal(eng.ws_tensor(B, 'Eo', (B, cfg.F, cfg.D)).cpu().numpy(), p32['outer_embeddings'][X])
+        for l in range(cfg.live_layers):
+            S = cfg.D >> (l + 1)
+            got = eng.ws_tensor(B, 'C', (B, S, S, Pp), index=l).cpu().numpy()
+            close(got, pad_channels(c['rs'][l], Pp), 'C[%d]' % l)
+        close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy(), c['t1'], 't1')
+        close(eng.ws_tensor(B, 'h1', (B, 32)).cpu().numpy(), c['h1'], 'h1')
     if cfg.linear_att:
         close(eng.ws_tensor(B, 'att', (B, cfg.F)).cpu().numpy(), c['a'], 'att')
     close(eng.ws_tensor(B, 'out', (B,)).cpu().numpy(), out_ref, 'out')
@@ -160,34 +258,56 @@ def test_backward_stages(name):
     yt = torch.from_numpy(y).cuda()
     eng.forward(ids, yt)
     torch.cuda.synchronize()
-    adopt_device_kinks(cfg, eng, B, c)
+    Pp = eng.tl.Pp
+    if name in HEAVY:      # the forward intermediates of the heavy case are checked here (one oracle pass for both)
+        for l in range(cfg.live_layers):
+            S = cfg.D >> (l + 1)
+            close(eng.ws_tensor(B, 'C', (B, S, S, Pp), index=l).cpu().numpy(), pad_channels(c['rs'][l], Pp), 'C[%d]' % l)
+        close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out')
+        close(eng.ws_tensor(B, 'out', (B,)).cpu().numpy(), out_ref, 'out')
+    if cfg.outer_conv:
+        n_kink = adopt_device_kinks(cfg, eng, B, c)
+        print('%s: %d relu decisions adopted from the device' % (name, n_kink))
     g = orc.backward(p64, c, dout, cfg)
     eng.backward(yt, B)
     torch.cuda.synchronize()
-    Pp = eng.tl.Pp
     sc = eng.ws_tensor(B, 'scalars', (16,)).cpu().numpy()
     close(sc[1:2], [L], 'loss')
-    close(eng.ws_tensor(B, 'dout', (B,)).cpu().numpy(), dout, 'dout')
-    close(eng.ws_tensor(B, 'dt1', (B, 2 * cfg.D - 2)).cpu().numpy(), g['_dt1'], 'dt1')
-    for l in range(cfg.live_layers - 1, -1, -1):
-        S = cfg.D >> (l + 1)
-        got = eng.ws_tensor(B, 'dC', (B, S, S, Pp), index=l).cpu().numpy()
-        close(got, pad_channels(g['_dC'][l], Pp), 'dC[%d]' % l)
-    close(eng.ws_tensor(B, 'dEo', (B, cfg.F, cfg.D)).cpu().numpy(), g['d_outer_rows'], 'dEo')
-    close(eng.ws_tensor(B, 'dEi', (B, cfg.F, cfg.K)).cpu().numpy(), g['d_inner_rows'], 'dEi')
-    close(eng.ws_tensor(B, 'dfb', (B, cfg.F)).cpu().numpy(), g['d_bias_rows'], 'dfb')
+    dsl = dout_slack(out_ref, y, cfg, p64)
+    close(eng.ws_tensor(B, 'dout', (B,)).cpu().numpy(), dout, 'dout', extra=dsl)
+    slack = inner_kink_slack(p64, c, dout, cfg)
+    # every per-example gradient is dL/dout_b times something that does not depend on dL/dout: the relative slack of
+    # dout_b (out_b - y_b cancels where the model fits) carries over to example b's rows of these tensors unchanged
+    rel_b = dsl / np.maximum(np.abs(dout), 1e-300)
+    per_ex = lambda ref: rel_b.reshape((B,) + (1,) * (ref.ndim - 1)) * np.abs(ref)
+    if cfg.outer_conv:
+        close(eng.ws_tensor(B, 'dt1', (B, 2 * cfg.D - 2)).cpu().numpy(), g['_dt1'], 'dt1', extra=per_ex(g['_dt1']))
+        for l in range(cfg.live_layers - 1, -1, -1):
+            S = cfg.D >> (l + 1)
+            got = eng.ws_tensor(B, 'dC', (B, S, S, Pp), index=l).cpu().numpy()
+            ref = pad_channels(g['_dC'][l], Pp)
+            close(got, ref, 'dC[%d]' % l, extra=per_ex(ref))
+        close(eng.ws_tensor(B, 'dEo', (B, cfg.F, cfg.D)).cpu().numpy(), g['d_outer_rows'], 'dEo', extra=per_ex(g['d_outer_rows']))
+    if cfg.inner_conv:
+        close(eng.ws_tensor(B, 'dEi', (B, cfg.F, cfg.K)).cpu().numpy(), g['d_inner_rows'], 'dEi',
+              extra=per_ex(g['d_inner_rows']) + slack.get('d_inner_rows', 0.0))
+    close(eng.ws_tensor(B, 'dfb', (B, cfg.F)).cpu().numpy(), g['d_bias_rows'], 'dfb', extra=per_ex(g['d_bias_rows']))
     got = eng.export_grad()
     for k, v in got.items():
         if k in g:
-            close(v, np.asarray(g[k]).reshape(v.shape), 'grad ' + k)
-        else:
-            assert not cfg.linear_att and k in ('bias_W', 'bias_b', 'dense_3_kernel', 'dense_3_bias'), k
+            close(v, np.asarray(g[k]).reshape(v.shape), 'grad ' + k, extra=None if k not in slack else slack[k].reshape(v.shape))
+        else:                               # parameters of a disabled branch receive no gradient (TF skips them)
+            assert not (cfg.linear_att and cfg.inner_conv and cfg.outer_conv), k
             assert np.all(v == 0), k
 
 
-@pytest.mark.parametrize('name', ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu',
-                                  'f12-d32-nolinatt', 'b1-elu', 'b257-relu', 'f20-d64-elu', 'f33-d32-relu'])
-@pytest.mark.parametrize('trained_like', [True, False])
+TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
+               'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
+               'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
+               'fm-only-nolinatt']
+
+
+@pytest.mark.parametrize('name,trained_like', [(n, t) for n in TRAIN_CASES for t in (True, False)] + [(n, True) for n in HEAVY])
 def test_train_step_matches_oracle(name, trained_like):
     """One sess.run((loss, optimizer)): post-update parameters AND Adagrad accumulators of every
     variable, including the sparse (duplicates-summed-first) table updates."""
@@ -197,10 +317,51 @@ def test_train_step_matches_oracle(name, trained_like):
     B = X.shape[0]
     eng.forward(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())   # same forward the step will redo
     torch.cuda.synchronize()
-    hook = lambda cache: adopt_device_kinks(cfg, eng, B, cache)
-    grads = oracle_dense_grads(p64, X, y, cfg, hook)
+    hook = (lambda cache: adopt_device_kinks(cfg, eng, B, cache)) if cfg.outer_conv else None
+    # ONE oracle pass: gradients in dense form (for the tolerance propagation) and the step itself
+    out, cache = orc.forward(p64, X, cfg)
+    if hook is not None:
+        hook(cache)
+    L, dout = orc.loss_and_grad(out, y.astype(np.float64), cfg, p64)
+    g = orc.backward(p64, cache, dout, cfg)
+    ids_flat = X.reshape(-1)
+    grads = {k: np.asarray(v) for k, v in g.items() if not k.startswith('d_') and not k.startswith('_')}
+    dgs = {k: 1e-5 * (np.abs(v) + max(float(np.sqrt(np.mean(v * v))), 1e-30)) for k, v in grads.items()}
+    slack = inner_kink_slack(p64, cache, dout, cfg)
+    for k in ('inner_layer_conv_weight_0', 'inner_layer_conv_bias_0'):
+        if k in slack:
+            dgs[k] = dgs[k] + slack[k].reshape(dgs[k].shape)
+    for tname, key in (('inner_embeddings', 'd_inner_rows'), ('outer_embeddings', 'd_outer_rows'), ('feature_bias', 'd_bias_rows')):
+        if key in g:
+            rows = g[key].reshape(ids_flat.shape[0], -1)
+            t, ta = np.zeros(p64[tname].shape), np.zeros(p64[tname].shape)
+            np.add.at(t, ids_flat, rows)
+            # every looked-up row gradient is held to 1e-5 * (|row element| + rms of the row-gradient tensor) in
+            # test_backward_stages; a table row's gradient is the SUM over its duplicates, so the bounds add up
+            np.add.at(ta, ids_flat, np.abs(rows) + float(np.sqrt(np.mean(rows * rows))))
+            grads[tname] = t
+            dgs[tname] = 1e-5 * ta
+            if key in slack:
+                np.add.at(dgs[tname], ids_flat, slack[key].reshape(ids_flat.shape[0], -1))
+    del cache
     acc = orc.init_accumulators(p64)
-    L, _ = orc.train_step(p64, acc, X, y.astype(np.float64), cfg, cache_hook=hook)
+    p_before = {k: np.array(v) for k, v in p64.items()}
+    for k, gk in grads.items():             # Adagrad (CFFM.py:523-524) from the gradients above: same as orc.train_step
+        if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+            continue
+        gk = gk.reshape(np.shape(p64[k]))
+        acc[k] = acc[k] + gk * gk
+        p64[k] = p64[k] - cfg.lr * gk / np.sqrt(acc[k])
+    for tname, key in (('inner_embeddings', 'd_inner_rows'), ('outer_embeddings', 'd_outer_rows'), ('feature_bias', 'd_bias_rows')):
+        if key in g:
+            orc.adagrad_sparse(p64[tname], acc[tname], ids_flat, g[key], cfg.lr)
+    if name == 'tiny-relu':                 # the hand-rolled update above IS orc.train_step (checked once, cheap case)
+        q = {k: np.array(v) for k, v in p_before.items()}
+        qa = orc.init_accumulators(q)
+        orc.train_step(q, qa, X, y.astype(np.float64), cfg, cache_hook=hook)
+        for k in q:
+            np.testing.assert_array_equal(np.asarray(q[k]), np.asarray(p64[k]), err_msg=k)
+            np.testing.assert_array_equal(np.asarray(qa[k]), np.asarray(acc[k]), err_msg=k)
     loss = eng.train_step(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())
     torch.cuda.synchronize()
     close(loss.cpu().numpy(), [L], 'loss')
@@ -212,7 +373,7 @@ def test_train_step_matches_oracle(name, trained_like):
         extra = acc_extra = None
         if k in grads:
             gk = grads[k].reshape(v.shape)
-            dg = 1e-5 * max(np.abs(gk).max(), 1e-30)
+            dg = dgs[k].reshape(v.shape)
             u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)          # monotonic: the worst case sits at g +- dg
             extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
             acc_extra = 2 * np.abs(gk) * dg + dg * dg
@@ -225,6 +386,26 @@ def test_train_step_matches_oracle(name, trained_like):
     for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
         np.testing.assert_array_equal(got[k][~touched], p32[k][~touched])
         assert np.all(gacc[k][~touched] == np.float32(1e-8))
+    # a disabled branch leaves its table and every parameter of its own exactly as they were
+    if not cfg.inner_conv:
+        np.testing.assert_array_equal(got['inner_embeddings'], p32['inner_embeddings'])
+        np.testing.assert_array_equal(got['dense_kernel'], p32['dense_kernel'])
+    if not cfg.outer_conv:
+        np.testing.assert_array_equal(got['outer_embeddings'], p32['outer_embeddings'])
+        np.testing.assert_array_equal(got['dense_1_kernel'], p32['dense_1_kernel'])
+
+
+def adagrad_step_slack(grads, acc_prev, lr, rel=1e-5):
+    """Bound on the parameter change of ONE Adagrad step caused by a gradient error of rel * (|g| + rms(g)): the update
+    u(g) = lr * g / sqrt(acc_prev + g^2) is monotonic in g, so the worst case sits at g +- dg.  With acc_prev = 1e-8
+    (first touch, CFFM.py:524) u amplifies a gradient error near g = 0 by up to lr * 1e4."""
+    out = {}
+    for k, gk in grads.items():
+        a = np.asarray(acc_prev[k], dtype=np.float64).reshape(gk.shape)
+        dg = rel * (np.abs(gk) + max(float(np.sqrt(np.mean(gk * gk))), 1e-30))
+        u = lambda t: lr * t / np.sqrt(a + t * t)
+        out[k] = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
+    return out
 
 
 def test_second_step_and_reproducibility():
@@ -235,8 +416,13 @@ def test_second_step_and_reproducibility():
     X2 = rng.integers(0, cfg.M, size=X.shape).astype(np.int32)
     p64 = to64(p32)
     acc = orc.init_accumulators(p64)
-    orc.train_step(p64, acc, X, y.astype(np.float64), cfg)
-    orc.train_step(p64, acc, X2, y.astype(np.float64), cfg)
+    y64 = y.astype(np.float64)
+    slack = {}
+    for Xs in (X, X2):                     # the gradient tolerance propagated through each of the two updates
+        g = oracle_dense_grads(p64, Xs, y, cfg)
+        for k, v in adagrad_step_slack(g, acc, cfg.lr, rel=2e-5).items():
+            slack[k] = slack.get(k, 0.0) + v
+        orc.train_step(p64, acc, Xs, y64, cfg)
     outs = []
     for _ in range(2):
         eng = engine_for(cfg, p32)
@@ -246,7 +432,7 @@ def test_second_step_and_reproducibility():
         outs.append(eng.export_params())
     for k, v in outs[0].items():
         np.testing.assert_array_equal(v, outs[1][k], err_msg=k)
-        close(v, p64[k].reshape(v.shape), 'param ' + k, tol=1e-4)
+        close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=None if k not in slack else slack[k].reshape(v.shape))
 
 
 @pytest.mark.parametrize('loss', ['mse', 'mae', 'log_loss', 'hybrid'])

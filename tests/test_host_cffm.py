@@ -108,3 +108,51 @@ def test_train_and_evaluate_end_to_end(tmp_path, caplog):
     m2.build_graph()
     r2mse, _ = m2.evaluate(data.Validation_data)
     assert r2mse == pytest.approx(rmse, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_evaluate_on_device_matches_oracle_and_sklearn(tmp_path):
+    """evaluate() (CFFM.py:583-615) keeps predictions, clip and metric sums on the device.  Against (a) the oracle's
+    forward + clipped RMSE/R2 on the same split and parameters, (b) sklearn's mean_squared_error / r2_score on the host
+    copy of the device's own predictions (1e-12: only the float64 summation order differs), with a ragged last block."""
+    import math
+    from sklearn.metrics import mean_squared_error, r2_score
+    from oracle import cffm_oracle as orc
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = LoadData(PATH, 'frappe', 'square_loss')
+    m = make(tmp_path, batch_size=7)
+    m.build_graph()
+    eng = m.engine
+    eng.fbias.normal_(0.0, 0.4)                                  # non-trivial outputs, some beyond the clip range
+    eng.outer.mul_(25.0)
+    for split in (data.Validation_data, data.Test_data):
+        rmse, r2 = m.evaluate(split)
+        X, Y = LoadData.packed(split)
+        y_true = Y.astype(np.float64)
+        pred = m.predict_split(split)
+        assert (pred < y_true.min()).any() or (pred > y_true.max()).any()      # the clip is exercised
+        bounded = np.minimum(np.maximum(pred, y_true.min()), y_true.max())
+        assert rmse == pytest.approx(math.sqrt(mean_squared_error(y_true, bounded)), rel=1e-12)
+        assert r2 == pytest.approx(r2_score(y_true, bounded), rel=1e-12, abs=1e-12)
+        p64 = {k: np.asarray(v, dtype=np.float64) for k, v in eng.export_params().items()}
+        out_ref, _ = orc.forward(p64, X, m.config)
+        o_rmse, o_r2 = orc.clipped_rmse_r2(out_ref, y_true)
+        assert rmse == pytest.approx(o_rmse, rel=1e-5) and r2 == pytest.approx(o_r2, rel=1e-4, abs=1e-5)
+
+
+@pytest.mark.gpu
+def test_train_leaves_the_callers_lists_shuffled_like_the_reference(tmp_path):
+    """CFFM.py:183 re-binds data.Train_data['X'] / ['Y'] to sklearn-shuffled lists (random_state 2021) every epoch."""
+    from sklearn.utils import shuffle
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = LoadData(PATH, 'frappe', 'square_loss')
+    X0, Y0 = list(data.Train_data['X']), list(data.Train_data['Y'])
+    m = make(tmp_path, epoch=3, batch_size=16, verbose=0)
+    m.train(data)
+    Xr, Yr = X0, Y0
+    for _ in range(3):
+        Xr, Yr = shuffle(Xr, Yr, random_state=2021)
+    assert data.Train_data['X'] == Xr and data.Train_data['Y'] == Yr
+    # and the device copy follows the same order: evaluate() on the re-bound lists does not re-pack
+    ids, y, _ = m._device_split(data.Train_data)
+    assert ids.cpu().numpy().tolist() == Xr
