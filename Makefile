@@ -1,4 +1,5 @@
-# Builds libcffm_hip.so (gfx950 only) and the oracle's compiled helpers.  hipcc cross-compiles without a GPU.
+# Builds libcffm_hip.so (gfx950 only), the host-side libfm reader and the pybind11 layer over the C ABI.  hipcc cross-compiles
+# without a GPU.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 SRC   := cffm_amd/csrc
@@ -9,7 +10,13 @@ ifdef PHASE_TIMERS
 CXXFLAGS += -DCFFM_PHASE_TIMERS
 endif
 
-all: $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so
+PYEXT := $(OUT)/_cffm_pybind$(shell python3-config --extension-suffix)
+
+all: $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so $(PYEXT)
+
+# thin pybind11 layer over the C ABI (north_star: "through a thin pybind11 C-ABI layer"); links the library next to it
+$(PYEXT): cffm_amd/csrc_host/pybind_module.cpp include/cffm_hip.h $(OUT)/libcffm_hip.so
+	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden $(shell python3 -m pybind11 --includes) $< -o $@ -L$(OUT) -lcffm_hip -Wl,-rpath,'$$ORIGIN'
 
 # host-only fast libfm reader
 $(OUT)/libcffm_libfm.so: cffm_amd/csrc_host/libfm_reader.cpp
@@ -25,5 +32,5 @@ $(OUT)/libcffm_hip.so: $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
 clean:
-	rm -rf build $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so
+	rm -rf build $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so $(PYEXT)
 .PHONY: all clean

@@ -49,7 +49,11 @@ WORKLOADS = {
                   text='book-crossing shape: 6 fields, 226336 features, dim 32, batch 512 per GPU, relu (README.md:20)'),
     'syn1m': dict(M=1000000, F=32, K=64, D=64, act='relu', B=8192,
                   text='synthetic stress shape: 32 fields, 1M features, dim 64, batch 8192 per GPU, relu'),
+    'syn10m': dict(M=10000000, F=32, K=64, D=64, act='relu', B=8192,
+                   text='BASELINE.json configs[4] per-GPU share: 32 fields, 10M features, dim 64, batch 8192 per GPU, relu '
+                        '(run with --tables sharded: embedding rows sharded r -> rank r % G)'),
 }
+BIG = ('syn1m', 'syn10m')
 
 
 def workload_cfg(name):
@@ -79,12 +83,16 @@ def measured_peaks(device):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ms = event_time_ms(lambda: hip.check(lib.cffm_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, st)), 20)
     copy_gbs = 2 * n / (ms * 1e-3) / 1e9
+    sink = torch.zeros(4096, device=device)
+    ms = event_time_ms(lambda: hip.check(lib.cffm_probe_read(C.c_void_p(src.data_ptr()), C.c_void_p(sink.data_ptr()), n, st)), 20)
+    read_gbs = n / (ms * 1e-3) / 1e9
     del src, dst
     torch.cuda.empty_cache()
     out = torch.zeros(4, device=device)
     flops = C.c_int64(0)
     ms = event_time_ms(lambda: hip.check(lib.cffm_probe_mfma(C.c_void_p(out.data_ptr()), 20000, C.byref(flops), st)), 5)
-    return {'hbm_copy_GBs': round(copy_gbs, 1), 'mfma_f32_TFLOPs': round(flops.value / (ms * 1e-3) / 1e12, 1)}
+    return {'hbm_copy_GBs': round(copy_gbs, 1), 'hbm_read_GBs': round(read_gbs, 1),
+            'mfma_f32_TFLOPs': round(flops.value / (ms * 1e-3) / 1e12, 1)}
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -100,8 +108,15 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def gather_roofline(device):
-    """cffm_gather on the stress shape of BASELINE.json configs[3]; timed with HIP events on the stream the
-    kernel is launched on (torch's current stream)."""
+    """The embedding-gather kernels on the stress shape of BASELINE.json configs[3] (32 fields, dim 64, 1 M features,
+    8192 rows, uniform ids: 516 MB of tables, beyond the Infinity Cache), timed with HIP events on the stream they are
+    launched on (torch's current stream).  achieved = ALGORITHMIC bytes (F*(K+D+1)*4 + F*4 per example) / time.
+
+    gather_packed_kernel   cffm_gather_packed: the owner side of a row-sharded lookup (ShardedStep), one packed record
+                           (inner | outer | bias) per id - the gather that is a launch of its own on a product path
+    gather_rows_kernel     cffm_gather: three separate outputs (the stage API / non-fused forward)
+    Both materialise their output, i.e. they write as many bytes as they read: see DESIGN.md for why the read-only form
+    (rows consumed in the kernel that fetches them) is VALU-bound, not HBM-bound, at this shape."""
     M, F, K, D, B = 1000000, 32, 64, 64, 8192
     lib = hip.load()
     shape = hip.Shape(M=M, F=F, K=K, D=D, act=0, linear_att=1, inner_conv=1, outer_conv=1, loss=0,
@@ -115,34 +130,47 @@ def gather_roofline(device):
     Ei = torch.empty((B, F, K), device=device)
     Eo = torch.empty((B, F, D), device=device)
     fb = torch.empty((B, F), device=device)
+    Wp = K + D + 4
+    packed = torch.empty((B * F, Wp), device=device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     state = {'i': 0}
 
-    def run():
+    def run_rows():
         i = state['i'] = (state['i'] + 1) % 8
         hip.check(lib.cffm_gather(C.byref(shape), C.byref(tabs), C.c_void_p(ids[i].data_ptr()), B,
                                   C.c_void_p(Ei.data_ptr()), C.c_void_p(Eo.data_ptr()), C.c_void_p(fb.data_ptr()), st))
-    ms = event_time_ms(run, 40)
+
+    def run_packed():
+        i = state['i'] = (state['i'] + 1) % 8
+        hip.check(lib.cffm_gather_packed(C.byref(shape), C.byref(tabs), C.c_void_p(ids[i].data_ptr()), B * F,
+                                         C.c_void_p(packed.data_ptr()), st))
+    ms_rows = event_time_ms(run_rows, 40)
     assert torch.equal(Eo[5], outer[ids[state['i']][5].long()])
+    ms_packed = event_time_ms(run_packed, 40)
+    idl = ids[state['i']].reshape(-1).long()
+    assert torch.equal(packed[:, K:K + D], outer[idl]) and torch.equal(packed[:, K + D], fbias[idl])
     bytes_per_launch = B * (F * (K + D + 1) * 4 + F * 4)
-    achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-    traffic = None                     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/)
+    achieved = bytes_per_launch / (ms_packed * 1e-3) / 1e9
+    traffic, source = None, None      # HBM bytes per launch: rocprofv3 PMC passes of this command, committed under profiles/
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_gather_pmc.json')) as fh:
-            traffic = int(json.load(fh)['hbm_bytes_per_launch'])
+        source = 'profiles/r02_gather_pmc.json'
+        with open(os.path.join(ROOT, source)) as fh:
+            traffic = int(json.load(fh)['gather_packed_kernel']['hbm_bytes_per_launch'])
     except Exception:
-        pass
-    del inner, outer, fbias, Ei, Eo, fb
+        traffic, source = None, None
+    del inner, outer, fbias, Ei, Eo, fb, packed
     torch.cuda.empty_cache()
-    return {'bound': 'hbm', 'kernel': 'gather_rows_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 2),
+    return {'bound': 'hbm', 'kernel': 'gather_packed_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
+            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms_packed * 1e3, 2),
+            'gather_rows_kernel': {'us_per_launch': round(ms_rows * 1e3, 2),
+                                   'achieved': round(bytes_per_launch / (ms_rows * 1e-3) / 1e9, 1)},
             'workload': 'synthetic libfm 32 fields dim 64 1M features batch 8192 uniform ids (tables 516 MB)'}
 
 
 def stage_times(eng, ids, y):
     """HIP-event time of every stage of one step at the bench workload (rank 0, diagnostic)."""
-    lib, s, B = eng.lib, eng.shape, ids.shape[0]
+    lib, s, B = hip.load(), eng.shape, ids.shape[0]
     buf, wl = eng.workspace(B)
     P = lambda t: C.c_void_p(t.data_ptr())
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -242,6 +270,8 @@ def main():
     ap.add_argument('--dp-mode', default='auto', choices=['auto', 'dense', 'gather'],
                     help='data-parallel exchange: dense image of the table gradients in one all-reduce (small vocabularies) or '
                          'all-gather of the row gradients; auto picks by size')
+    ap.add_argument('--blocks', type=int, default=0,
+                    help='timed blocks of --steps steps; the median block is reported (default 25, 1 for the big shapes)')
     ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
@@ -263,50 +293,67 @@ def main():
     torch.cuda.set_device(device)
 
     cfg, B = workload_cfg(args.workload)                # B per GPU: weak scaling, global batch = B * N
-    n_pool = N_POOL if args.workload != 'syn1m' else 4
+    big = args.workload in BIG
+    n_pool = N_POOL if not big else 4
     Xh, yh = synth.batches(cfg.M, cfg.F, B, n_pool * world, seed=2021, dist=args.dist)
     Xh, yh = Xh[rank::world], yh[rank::world]            # every rank its own shard of every global batch
     X = torch.from_numpy(Xh).to(device)
     y = torch.from_numpy(yh).to(device)
+    # vocabularies of >= 5 M rows: the tables are drawn on the device (a host draw + copy of 5 GB would dominate start-up)
+    on_device = cfg.M >= 5000000
 
     if args.tables == 'sharded':
         import copy
         from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
         lcfg = copy.copy(cfg)
         lcfg.M = local_rows_count(cfg.M, rank, world)
-        eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=2021), rank, world), device=str(device))
+        if on_device:
+            eng = HipEngine(lcfg, params='device', seed=2021 + rank, device=str(device))
+        else:
+            eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=2021), rank, world), device=str(device))
         sh = ShardedStep(eng)
-        step = lambda i: sh.train_step(X[i % n_pool], y[i % n_pool])
+        # the routing plan of the next batch is issued one step ahead (its per-owner counts are on the host before needed)
+        step = lambda i: sh.train_step(X[i % n_pool], y[i % n_pool], next_ids=X[(i + 1) % n_pool])
         barrier = lambda: dist.barrier()
     elif world > 1 or args.force_dp:
         from cffm_amd.dist import DataParallelStep
-        eng = HipEngine(cfg, seed=2021, device=str(device))
+        eng = HipEngine(cfg, params='device' if on_device else None, seed=2021, device=str(device))
         dp = DataParallelStep(eng, use_graph=args.graph, mode=args.dp_mode)
         step = lambda i: dp.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: dist.barrier()
     else:
-        eng = HipEngine(cfg, seed=2021, device=str(device))
+        eng = HipEngine(cfg, params='device' if on_device else None, seed=2021, device=str(device))
         step = lambda i: eng.train_step(X[i % n_pool], y[i % n_pool])
         barrier = lambda: None
 
+    # W untimed warm-up steps, then blocks of EXACTLY K timed steps, each bracketed by barrier + synchronize on both sides
+    # and reduced with MAX over the ranks.  A block of 20 frappe steps is 2.4 ms, so one block decides nothing: the
+    # reported figure is the MEDIAN block (all block times are in ms_per_step_blocks); the big shapes run one block.
+    n_blocks = args.blocks if args.blocks > 0 else (1 if big else 25)
     for i in range(args.warmup):
         step(i)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_pg:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    block_dt = []
+    it = args.warmup
+    for _ in range(n_blocks):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(it + i)
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        it += args.steps
+        if use_pg:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_dt.append(dt)
+    dt = float(np.median(block_dt))
     loss = float(eng.loss_buf[0].item())
     if not np.isfinite(loss):
         raise SystemExit('bench.py: loss is not finite')
-    if args.workload == 'syn1m':
+    if big:
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -315,6 +362,7 @@ def main():
             'value': round(B * world * args.steps / dt, 1), 'unit': 'examples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'blocks': n_blocks, 'ms_per_step_blocks': [round(v / args.steps * 1e3, 4) for v in block_dt],
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': WORKLOADS[args.workload]['text'],
                        'global_batch': B * world, 'id_distribution': args.dist, 'tables': args.tables,
@@ -325,6 +373,7 @@ def main():
         res['step_flops'] = {'reference_algorithm_TFLOPs': round(tf, 2), 'mfma_f32_peak_TFLOPs': MFMA_F32_PEAK_TFLOPS * world,
                              'frac': round(tf / (MFMA_F32_PEAK_TFLOPS * world), 4),
                              'note': 'conv0 runs factorised (rank-1 input channels), so executed FLOPs are lower'}
+        res['binding'] = hip.binding_name()
         if world == 1 and not args.quick and args.tables == 'replicated' and not args.force_dp:
             # the same loop with the host-side batcher of CFFM.train in it (random start on the host, slice of the
             # device-resident split): SURVEY 8d's "second figure including host batching"
@@ -333,16 +382,17 @@ def main():
             rs = np.random.RandomState(2021)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(args.steps):
+            nb = max(args.steps, 200) if not big else args.steps
+            for i in range(nb):
                 s0 = rs.randint(0, nrow - B)
                 eng.train_step(Xall[s0:s0 + B], yall[s0:s0 + B])
             torch.cuda.synchronize()
-            res['value_with_host_batching'] = round(B * args.steps / (time.perf_counter() - t0), 1)
+            res['value_with_host_batching'] = round(B * nb / (time.perf_counter() - t0), 1)
             res['stage_us'] = stage_times(eng, X[0], y[0])
             del X, y
             res['roofline'] = gather_roofline(device)
             res['roofline']['measured_peaks'] = measured_peaks(device)
-            if not args.no_cpu_baseline and args.workload != 'syn1m':
+            if not args.no_cpu_baseline and not big:
                 res['cpu_baseline'] = cpu_baseline(cfg, Xh, yh)
         print(json.dumps(res), flush=True)
     if use_pg:

@@ -137,7 +137,7 @@ class CFFM(object):
         import torch
         key = id(data)
         hit = self._packed.get(key)
-        if hit is not None and hit[2] is data['X']:
+        if hit is not None and hit[2] is self._token(data):
             return hit[0], hit[1], hit[3]
         X, Y = DATA.LoadData.packed(data)
         if X.shape[1] != self.num_field:
@@ -145,8 +145,15 @@ class CFFM(object):
         dev = self.engine.device
         ids, y = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
         span = (float(Y.min()), float(Y.max())) if Y.size else (0.0, 0.0)      # clip range of evaluate(), CFFM.py:607-609
-        self._packed[key] = (ids, y, data['X'], span)
+        self._packed[key] = (ids, y, self._token(data), span)
         return ids, y, span
+
+    @staticmethod
+    def _token(data):
+        """What identifies the current content of a split: the loader's packed array while its lists have not been built
+        or re-bound (cffm_amd.LoadData._Split), else the 'X' list object itself."""
+        arrays = getattr(data, '_arrays', None)
+        return arrays[0] if arrays is not None else data['X']
 
     # ---- training loop (CFFM.py:157-228) -------------------------------------------------------------
     def train(self, data):
@@ -183,7 +190,7 @@ class CFFM(object):
                 torch.cuda.synchronize()
                 t2 = time()
                 self.examples_per_sec.append(total_batch * self.batch_size / max(t2 - t1, 1e-9))
-                self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'], span)   # evaluate() sees the shuffled order
+                self._packed[id(data.Train_data)] = (ids, y, self._token(data.Train_data), span)   # evaluate() sees the shuffled order
                 train_rmse, train_r2 = self.evaluate(data.Train_data)
                 valid_rmse, valid_r2 = self.evaluate(data.Validation_data)
                 test_rmse, test_r2 = self.evaluate(data.Test_data)
@@ -211,7 +218,7 @@ class CFFM(object):
                 X0, Y0 = data.Train_data['X'], data.Train_data['Y']
                 data.Train_data['X'] = [X0[i] for i in order]
                 data.Train_data['Y'] = [Y0[i] for i in order]
-                self._packed[id(data.Train_data)] = (ids, y, data.Train_data['X'], span)
+                self._packed[id(data.Train_data)] = (ids, y, self._token(data.Train_data), span)
 
     # ---- evaluation (CFFM.py:583-615) ------------------------------------------------------------------
     def evaluate(self, data):

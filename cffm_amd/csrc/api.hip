@@ -207,6 +207,10 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
     cffm_ws_layout_t wl; cffm_theta_layout_t tl;
     cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
     char* w = (char*)ws;
+    if (!rows) {        // the caller packs the row gradients itself (cffm_pack_rows_dedup): only the loss-term sum is moved
+        hipError_t e = hipMemcpyAsync(grad + tl.n, w + wl.scalars, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return e == hipSuccess ? 0 : (int)e;
+    }
     return cffm_pack_rows(s, ids, B, (const float*)(w + wl.dEi), (const float*)(w + wl.dEo), (const float*)(w + wl.dfb),
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }

@@ -118,3 +118,145 @@ int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const f
     CFFM_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- row-sharded tables: the owner side of a lookup, the requester side of its answer, and the duplicate-summed
+// ---- gradient message (cffm_amd/dist.py ShardedStep; SURVEY 8e collectives 1-3) -----------------------------------
+// A looked-up row travels as ONE packed record of cffm_packed_row_floats() = K + D + 4 floats: (inner row | outer row |
+// feature_bias, 0, 0, 0) - 16-byte aligned, so both ends move it in 16-byte pieces and the 4-byte feature_bias row rides
+// in the same lanes instead of a scalar gather of its own.
+extern "C" int32_t cffm_packed_row_floats(const cffm_shape_t* s) { return s ? s->K + s->D + 4 : 0; }
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_packed_kernel(const float* __restrict__ inner, const float* __restrict__ outer,
+                                                            const float* __restrict__ fbias, const int32_t* __restrict__ rows,
+                                                            int64_t n, int K4, int D4, int M, float* __restrict__ out) {
+    const int CH = K4 + D4 + 1;
+    const float inv_ch = 1.f / (float)CH;
+    const int64_t total = n * CH, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += stride * UNROLL) {
+        f32x4 v[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {                       // UNROLL independent 16-byte pieces in flight per lane
+            const int64_t g = g0 + u * stride;
+            ok[u] = g < total;
+            if (ok[u]) {
+                // g / CH without the 64-bit division sequence: exact for the < 2^31 chunk counts one launch sees
+                int64_t slot = (int64_t)(((double)g + 0.5) * (double)inv_ch);
+                int ch = (int)(g - slot * CH);
+                if (ch < 0) { --slot; ch += CH; } else if (ch >= CH) { ++slot; ch -= CH; }
+                int id = rows[slot];
+                id = id < 0 ? 0 : (id >= M ? M - 1 : id);        // clamp: a bad id must not fault the GPU
+                if (ch < K4) v[u] = *(reinterpret_cast<const f32x4*>(inner) + (int64_t)id * K4 + ch);
+                else if (ch < K4 + D4) v[u] = *(reinterpret_cast<const f32x4*>(outer) + (int64_t)id * D4 + (ch - K4));
+                else v[u] = (f32x4){fbias[id], 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            if (ok[u]) *(reinterpret_cast<f32x4*>(out) + g0 + u * stride) = v[u];
+    }
+}
+
+extern "C" int cffm_gather_packed(const cffm_shape_t* s, const cffm_tables_t* t, const int32_t* rows, int64_t n, float* out,
+                                  void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!t || !rows || !out || (s->D & 3) || (s->K & 3)) return CFFM_ERR_BAD_SHAPE;
+    const int K4 = s->K / 4, D4 = s->D / 4;
+    const int64_t total = n * (K4 + D4 + 1);
+    if (total >= (1ll << 31)) return CFFM_ERR_BAD_SHAPE;
+    int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((gather_packed_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t->inner_emb, t->outer_emb,
+                       t->feat_bias, rows, n, K4, D4, s->M, out);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// requester side: slot i of the batch takes packed record pos[i] (duplicates of one id share a record) -> ws.Ei / ws.Eo / ws.fb
+__global__ __launch_bounds__(256) void stage_packed_kernel(const float* __restrict__ packed, const int32_t* __restrict__ pos,
+                                                           int64_t n_slots, int64_t n_records, int K4, int D4,
+                                                           float* __restrict__ Ei, float* __restrict__ Eo, float* __restrict__ fb) {
+    const int CH = K4 + D4 + 1;
+    const float inv_ch = 1.f / (float)CH;
+    const int64_t total = n_slots * CH, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        int64_t slot = (int64_t)(((double)g + 0.5) * (double)inv_ch);
+        int ch = (int)(g - slot * CH);
+        if (ch < 0) { --slot; ch += CH; } else if (ch >= CH) { ++slot; ch -= CH; }
+        int64_t r = pos ? (int64_t)pos[slot] : slot;
+        r = r < 0 ? 0 : (r >= n_records ? n_records - 1 : r);
+        const f32x4 v = *(reinterpret_cast<const f32x4*>(packed) + r * CH + ch);
+        if (ch < K4) { if (Ei) *(reinterpret_cast<f32x4*>(Ei) + slot * K4 + ch) = v; }
+        else if (ch < K4 + D4) { if (Eo) *(reinterpret_cast<f32x4*>(Eo) + slot * D4 + (ch - K4)) = v; }
+        else fb[slot] = v[0];
+    }
+}
+
+extern "C" int cffm_stage_packed(const cffm_shape_t* s, const float* packed, const int32_t* pos, int64_t n_records, int32_t B,
+                                 void* ws, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!packed || !ws || n_records <= 0 || (s->D & 3) || (s->K & 3)) return CFFM_ERR_BAD_SHAPE;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    const int K4 = s->K / 4, D4 = s->D / 4;
+    const int64_t n_slots = (int64_t)B * s->F, total = n_slots * (K4 + D4 + 1);
+    if (total >= (1ll << 31)) return CFFM_ERR_BAD_SHAPE;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(stage_packed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, pos, n_slots, n_records, K4,
+                       D4, s->inner_conv ? (float*)(w + wl.Ei) : nullptr, s->outer_conv ? (float*)(w + wl.Eo) : nullptr,
+                       (float*)(w + wl.fb));
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Gradient message of a row-sharded step with the duplicates of one id summed BEFORE the exchange ("all-to-all
+// of deduplicated ids").  order[q] = slot at sorted position q (sorted by (owner, local row), stable: slots ascend inside
+// a segment), uniq[q] = index of that position's distinct id; a wavefront per segment head sums its segment in slot order
+// (bitwise reproducible) into record uniq[q] of out: (local row bits | dEi | dEo | dfb), the row format cffm_dp_apply takes.
+__global__ __launch_bounds__(256) void pack_rows_dedup_kernel(const int32_t* __restrict__ local_ids, const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ uniq, int64_t n, int K, int D,
+                                                              const float* __restrict__ dEi, const float* __restrict__ dEo,
+                                                              const float* __restrict__ dfb, float* __restrict__ out) {
+    const int64_t q0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q0 >= n) return;
+    const int u = uniq[q0];
+    if (q0 > 0 && uniq[q0 - 1] == u) return;                     // not a segment head
+    const int W = 1 + K + D + 1;
+    float* o = out + (int64_t)u * W;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= W) continue;
+        if (c == 0) { o[0] = __int_as_float(local_ids[order[q0]]); continue; }
+        float g = 0.f;
+        for (int64_t q = q0; q < n && uniq[q] == u; ++q) {
+            const int64_t sl = order[q];
+            g += c <= K ? (dEi ? dEi[sl * K + (c - 1)] : 0.f) : (c <= K + D ? (dEo ? dEo[sl * D + (c - 1 - K)] : 0.f) : dfb[sl]);
+        }
+        o[c] = g;
+    }
+}
+
+extern "C" int cffm_pack_rows_dedup(const cffm_shape_t* s, const int32_t* local_ids, const int32_t* order, const int32_t* uniq,
+                                    int32_t B, void* ws, float* out, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!local_ids || !order || !uniq || !ws || !out) return CFFM_ERR_BAD_SHAPE;
+    cffm_ws_layout_t wl;
+    cffm_ws_layout(s, B, &wl);
+    char* w = (char*)ws;
+    const int64_t n = (int64_t)B * s->F;
+    hipLaunchKernelGGL(pack_rows_dedup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, local_ids, order,
+                       uniq, n, s->K, s->D, s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
+                       s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb), out);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}

@@ -182,50 +182,111 @@ def shard_params(params, rank, world):
     return out
 
 
+class _Plan(object):
+    """Routing of one batch through the row-sharded tables: everything the exchange needs that depends only on the ids.
+    Built on the device without a host sync; the per-destination counts reach the host through an asynchronous copy into
+    pinned memory and are only waited for when the step that uses them starts (one step later when prefetched)."""
+    __slots__ = ('ids', 'B', 'F', 'local_ids', 'order', 'uniq', 'pos', 'send_rows', 'counts_host', 'event', '_sc', '_rc')
+
+    def counts(self):
+        if self._sc is None:
+            if self.event is not None:
+                self.event.synchronize()
+            c = self.counts_host.tolist()
+            self._sc, self._rc = [int(v) for v in c[0]], [int(v) for v in c[1]]
+        return self._sc, self._rc
+
+
 class ShardedStep(object):
     """Training step with ROW-SHARDED tables (vocabulary beyond one GPU's HBM; cfg5 of BASELINE.json): dense parameters
     replicated, row r of the three tables and of their Adagrad accumulators on rank r % G at local row r // G.
 
-        route ids by owner -> all-to-all (ids) -> owner-side gather -> all-to-all (rows back, one packed message)
-        -> forward_rows / backward_unscaled (local) -> all-reduce [dense grad | loss sum]
-        -> all-to-all (packed row gradients, keyed by the owner's local row) -> dp_apply on the owner:
-           1/L, dense Adagrad (identical on every rank), duplicates-summed-first sparse Adagrad over the rows it owns
+        plan (ids only, device-side, may run one step AHEAD): distinct (owner, local row) pairs of the batch in owner
+            order, slot -> distinct-index map, per-owner counts + their all-to-all
+        all-to-all (DISTINCT local rows)  -> owner-side cffm_gather_packed -> all-to-all (packed rows back)
+        -> cffm_stage_packed (duplicates re-expanded into ws.Ei/Eo/fb) -> forward / backward_unscaled (local)
+        -> all-reduce [dense grad | loss sum]
+        -> cffm_pack_rows_dedup (duplicates of an id summed in slot order) -> all-to-all (row gradients, keyed by the
+           owner's local row) -> dp_apply on the owner: 1/L, dense Adagrad (identical on every rank), duplicates across
+           ranks summed first, then one sparse Adagrad update per row it owns
 
-    Exchange volume scales with the B*F lookups of the batch, never with the vocabulary.  ``compute`` owns a LOCAL
-    engine (cfg.M = local_rows_count): HipEngine in the product, the oracle in the CPU tests."""
+    Exchange volume scales with the DISTINCT lookups of the batch, never with the vocabulary.  The only host
+    synchronisation is the read of the per-owner counts (RCCL's all-to-all takes its split sizes from the host); with
+    ``train_step(ids, y, next_ids=...)`` the plan of the next batch is issued before this step's kernels, so that read
+    never waits.  ``compute`` owns a LOCAL engine (cfg.M = local_rows_count): HipEngine in the product, the oracle in the
+    CPU tests."""
 
-    def __init__(self, compute, group=None):
+    def __init__(self, compute, group=None, dedup=True):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.dedup = dedup
+        self._ahead = None
 
     def _a2a(self, send, send_counts, recv_counts):
         recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group)
         return recv
 
-    def train_step(self, ids, y):
-        c, G = self.c, self.world
+    def plan(self, ids):
+        G = self.world
         B, F = ids.shape
-        Bg = B * G
-        flat = ids.reshape(-1).long()
-        perm, send_counts = route_ids(flat, G)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()              # the one host sync of the step
-        # 1) ask the owners for rows, by their local row index
-        want = (flat[perm] // G).to(torch.int32).contiguous()
-        asked = self._a2a(want, sc, rc)
-        rows = c.gather_packed(asked)                                    # [m, K+D+1] on the owner
-        got = self._a2a(rows, rc, sc)                                    # back in routed order
-        staged = torch.empty_like(got)
-        staged[perm] = got                                               # caller's (example, field) order
-        K, D = c.cfg.K, c.cfg.D
-        c.forward_rows(staged[:, :K].contiguous(), staged[:, K:K + D].contiguous(), staged[:, K + D].contiguous(), y, B)
-        # 2) local backward, gradients keyed by the owner's local row
-        local_ids = (flat // G).to(torch.int32).reshape(B, F).contiguous()
-        grad, packed = c.backward_unscaled(local_ids, y, B, Bg)
+        n = B * F
+        dev = ids.device
+        flat = ids.reshape(-1).to(torch.int64)
+        owner, local = flat % G, flat // G
+        comp = owner * (1 << 32) + local                              # owner-major, then the owner's local row
+        scomp, order = torch.sort(comp, stable=True)                  # slots ascend inside a run of equal keys
+        if self.dedup:
+            head = torch.ones(n, dtype=torch.bool, device=dev)
+            head[1:] = scomp[1:] != scomp[:-1]
+            uniq = torch.cumsum(head, 0) - 1                          # distinct-id index of every sorted position
+            send_rows = torch.zeros(n, dtype=torch.int64, device=dev)
+            send_rows[uniq] = scomp & 0xffffffff                      # capacity n, the first #distinct entries are used
+            counts = torch.zeros(G, dtype=torch.int64, device=dev).index_add_(0, scomp >> 32, head.to(torch.int64))
+        else:
+            uniq = torch.arange(n, dtype=torch.int64, device=dev)
+            send_rows = scomp & 0xffffffff
+            counts = torch.bincount(owner, minlength=G)
+        pos = torch.empty(n, dtype=torch.int64, device=dev)
+        pos[order] = uniq                                             # slot -> record of the answer
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)
+        both = torch.stack([counts, recv_counts])
+        p = _Plan()
+        p.ids, p.B, p.F = ids, B, F
+        p.local_ids = local.to(torch.int32).reshape(B, F).contiguous()
+        p.order, p.uniq, p.pos = order.to(torch.int32), uniq.to(torch.int32), pos.to(torch.int32)
+        p.send_rows = send_rows.to(torch.int32)
+        p._sc = p._rc = None
+        if dev.type == 'cuda':
+            p.counts_host = torch.empty((2, G), dtype=torch.int64, pin_memory=True)
+            p.counts_host.copy_(both, non_blocking=True)
+            p.event = torch.cuda.Event()
+            p.event.record()
+        else:
+            p.counts_host, p.event = both, None
+        return p
+
+    def train_step(self, ids, y, next_ids=None):
+        c = self.c
+        plan, self._ahead = self._ahead, None
+        if plan is None or plan.ids is not ids:
+            plan = self.plan(ids)
+        if next_ids is not None:
+            self._ahead = self.plan(next_ids)         # before this step's kernels: its counts are on the host long before needed
+        B, Bg = plan.B, plan.B * self.world
+        sc, rc = plan.counts()
+        u = sum(sc)
+        # 1) ask the owners for the DISTINCT rows, by their local row index; the answer is one packed record per row
+        asked = self._a2a(plan.send_rows[:u], sc, rc)
+        got = self._a2a(c.gather_packed(asked), rc, sc)                  # [u, K+D+4] in distinct-id order
+        c.stage_packed(got, plan.pos, B)                                 # duplicates re-expanded: ws.Ei / ws.Eo / ws.fb
+        c.forward_staged(y, B)
+        # 2) local backward without 1/L, gradients keyed by the owner's local row, duplicates summed before they travel
+        grad = c.backward_unscaled(plan.local_ids, y, B, Bg, pack=False)[0]
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
-        recv = self._a2a(packed[perm].contiguous(), sc, rc)
+        rows = c.pack_rows_dedup(plan.local_ids, plan.order, plan.uniq, B)
+        recv = self._a2a(rows[:u], sc, rc)
         return c.dp_apply(grad, recv, Bg)

@@ -24,7 +24,8 @@ _THETA_MEMBERS = [
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Borrowed device pointer of a torch tensor as a plain integer (0 for None): what both bindings take."""
+    return t.data_ptr() if t is not None else 0
 
 
 class HipEngine(object):
@@ -32,7 +33,8 @@ class HipEngine(object):
         if not torch.cuda.is_available():
             raise RuntimeError('cffm_amd.HipEngine needs an MI355X (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
-        self.lib = hip.load()
+        hip.load()
+        self.lib = hip.fast()                         # pybind11 layer (ctypes when it is not built): integer pointers
         self.cfg = cfg
         self.device = torch.device(device)
         self.shape = hip.make_shape(cfg)
@@ -73,6 +75,11 @@ class HipEngine(object):
         self.tables = hip.Tables(self.inner.data_ptr(), self.outer.data_ptr(), self.fbias.data_ptr())
         self.tables_acc = hip.Tables(self.inner_acc.data_ptr(), self.outer_acc.data_ptr(), self.fbias_acc.data_ptr())
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        # addresses of the small host structs (kept alive by self)
+        self._s = C.addressof(self.shape)
+        self._t = C.addressof(self.tables)
+        self._ta = C.addressof(self.tables_acc)
+        self._ta2 = C.addressof(self.tables_acc2) if self.tables_acc2 is not None else 0
         self.load_params(params)
         if device_tables:
             gen = torch.Generator(device=dev).manual_seed(int(seed))
@@ -215,7 +222,7 @@ class HipEngine(object):
         return buf[int(off):int(off) + n * itemsize].view(dtype).reshape(shape)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
     def _ids(ids):
@@ -232,7 +239,7 @@ class HipEngine(object):
             return torch.empty(0, dtype=torch.float32, device=self.device)
         buf, _ = self.workspace(B)
         out = torch.empty(B, dtype=torch.float32, device=self.device)
-        hip.check(self.lib.cffm_predict(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
+        hip.check(self.lib.cffm_predict(self._s, self._t, _ptr(self.theta), _ptr(ids),
                                         B, _ptr(buf), _ptr(out), self._stream()))
         return out
 
@@ -267,12 +274,12 @@ class HipEngine(object):
         if self.cfg.optimizer != 'AdagradOptimizer':
             self.opt_step += 1
             hip.check(self.lib.cffm_train_step_opt(
-                C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
-                C.byref(self.tables_acc2) if self.tables_acc2 is not None else None, _ptr(self.theta),
+                self._s, self._t, self._ta,
+                self._ta2, _ptr(self.theta),
                 _ptr(self.theta_acc), _ptr(self.theta_acc2), _ptr(self.grad), _ptr(ids), _ptr(y), B, _ptr(buf),
                 _ptr(self.loss_buf), self.opt_step, self._stream()))
             return self.loss_buf
-        hip.check(self.lib.cffm_train_step(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+        hip.check(self.lib.cffm_train_step(self._s, self._t, self._ta,
                                            _ptr(self.theta), _ptr(self.theta_acc), _ptr(self.grad), _ptr(ids),
                                            _ptr(y), B, _ptr(buf), _ptr(self.loss_buf), self._stream()))
         return self.loss_buf
@@ -282,57 +289,77 @@ class HipEngine(object):
         ids = self._ids(ids)
         B = ids.shape[0]
         buf, _ = self.workspace(B)
-        hip.check(self.lib.cffm_forward(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids),
+        hip.check(self.lib.cffm_forward(self._s, self._t, _ptr(self.theta), _ptr(ids),
                                         _ptr(y), B, _ptr(buf), self._stream()))
 
     def gather_packed(self, local_rows):
-        """Owner side of a row-sharded lookup: int32 [m] local rows -> [m, K+D+1] = (inner | outer | bias) rows."""
+        """Owner side of a row-sharded lookup: int32 [m] local rows -> [m, K+D+4] packed records
+        (inner | outer | bias, 0, 0, 0), ONE kernel (cffm_gather_packed)."""
         m = int(local_rows.numel())
-        K, D = self.cfg.K, self.cfg.D
-        out = torch.empty((m, K + D + 1), dtype=torch.float32, device=self.device)
+        Wp = self.cfg.K + self.cfg.D + 4
+        out = torch.empty((m, Wp), dtype=torch.float32, device=self.device)
         if m:
-            F = self.cfg.F
-            Bp = -(-m // F)                                  # cffm_gather takes whole [B,F] id blocks: pad with row 0
-            ids = torch.zeros(Bp * F, dtype=torch.int32, device=self.device)
-            ids[:m] = local_rows.reshape(-1)
-            Ei, Eo, fb = self.gather(ids.reshape(Bp, F))
-            out[:, :K] = Ei.reshape(Bp * F, K)[:m]
-            out[:, K:K + D] = Eo.reshape(Bp * F, D)[:m]
-            out[:, K + D] = fb.reshape(Bp * F)[:m]
+            rows = self._ids(local_rows.reshape(-1))
+            hip.check(self.lib.cffm_gather_packed(self._s, self._t, _ptr(rows), m, _ptr(out), self._stream()))
         return out
 
+    def stage_packed(self, packed, pos, B):
+        """Requester side: slot i of the batch takes record pos[i] of packed [n_records, K+D+4] -> ws.Ei / ws.Eo / ws.fb."""
+        buf, _ = self.workspace(B)
+        pos = self._ids(pos.reshape(-1)) if pos is not None else None
+        hip.check(self.lib.cffm_stage_packed(self._s, _ptr(packed), _ptr(pos), int(packed.shape[0]), int(B), _ptr(buf),
+                                             self._stream()))
+
+    def forward_staged(self, y, B):
+        """cffm_forward over rows that are already staged in the workspace (tab = NULL)."""
+        buf, _ = self.workspace(B)
+        hip.check(self.lib.cffm_forward(self._s, 0, _ptr(self.theta), 0, _ptr(y), int(B), _ptr(buf), self._stream()))
+
     def forward_rows(self, Ei, Eo, fb, y, B=None):
-        """Forward from rows that are already looked up (row-sharded tables, cffm_amd/dist.py): Ei [B,F,K], Eo [B,F,D],
-        fb [B,F] are staged into the workspace and cffm_forward runs without its gather."""
+        """Forward from rows that are already looked up, given as three tensors Ei [B,F,K], Eo [B,F,D], fb [B,F]."""
         F = self.cfg.F
         B = Ei.numel() // (F * self.cfg.K) if B is None else B
-        buf, _ = self.workspace(B)
+        self.workspace(B)
         self.ws_tensor(B, 'Ei', (B, F, self.cfg.K)).copy_(Ei.reshape(B, F, self.cfg.K))
         self.ws_tensor(B, 'Eo', (B, F, self.cfg.D)).copy_(Eo.reshape(B, F, self.cfg.D))
         self.ws_tensor(B, 'fb', (B, F)).copy_(fb.reshape(B, F))
-        hip.check(self.lib.cffm_forward(C.byref(self.shape), None, _ptr(self.theta), None, _ptr(y), B, _ptr(buf),
-                                        self._stream()))
+        self.forward_staged(y, B)
+
+    def pack_rows_dedup(self, local_ids, order, uniq, B):
+        """Row-gradient message with the duplicates of an id summed first (cffm_pack_rows_dedup): returns [B*F, 1+K+D+1]
+        of which the first #distinct records are valid."""
+        buf, _ = self.workspace(B)
+        W = 1 + self.cfg.K + self.cfg.D + 1
+        key = ('dedup', B)
+        out = self._ws.get(key)
+        if out is None:
+            out = torch.empty((B * self.cfg.F, W), dtype=torch.float32, device=self.device)
+            self._ws[key] = out
+        hip.check(self.lib.cffm_pack_rows_dedup(self._s, _ptr(self._ids(local_ids.reshape(-1))), _ptr(order), _ptr(uniq), int(B),
+                                                _ptr(buf), _ptr(out), self._stream()))
+        return out
 
     def backward(self, y, B, B_global=None):
         buf, _ = self.workspace(B)
-        hip.check(self.lib.cffm_backward(C.byref(self.shape), _ptr(self.theta), _ptr(y), int(B),
+        hip.check(self.lib.cffm_backward(self._s, _ptr(self.theta), _ptr(y), int(B),
                                          int(B if B_global is None else B_global), _ptr(buf), _ptr(self.grad),
                                          self._stream()))
 
     # ---- data-parallel halves with late loss normalisation (cffm_amd/dist.py) ----------------------------------
-    def backward_unscaled(self, ids, y, B, B_global):
+    def backward_unscaled(self, ids, y, B, B_global, pack=True):
         """Backward with dL/dout = (out - y) / B_global.  Returns (grad_full [n+4] with this rank's loss-term sum at
         index n, rows [B*F, 1+K+D+1] = (id bits | dEi | dEo | dfb)) - the operands of ONE all-reduce and ONE
-        all-gather."""
+        all-gather.  pack=False leaves the row gradients in the workspace (rows is None): the row-sharded step packs
+        them itself with the duplicates summed (pack_rows_dedup)."""
         ids = self._ids(ids)
         buf, _ = self.workspace(B)
         W = 1 + self.cfg.K + self.cfg.D + 1
         key = ('rows', B)
-        rows = self._ws.get(key)
-        if rows is None:
+        rows = self._ws.get(key) if pack else None
+        if rows is None and pack:
             rows = torch.empty((B * self.cfg.F, W), dtype=torch.float32, device=self.device)
             self._ws[key] = rows
-        hip.check(self.lib.cffm_backward_unscaled(C.byref(self.shape), _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
+        hip.check(self.lib.cffm_backward_unscaled(self._s, _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
                                                   int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(rows),
                                                   self._stream()))
         return self._grad_full, rows
@@ -349,7 +376,7 @@ class HipEngine(object):
         if block is None:
             block = torch.empty(B * self.cfg.F * (W + 2), dtype=torch.float32, device=self.device)
             self._ws[key] = block
-        hip.check(self.lib.cffm_dp_local(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
+        hip.check(self.lib.cffm_dp_local(self._s, self._t, _ptr(self.theta), _ptr(ids), _ptr(y), int(B),
                                          int(B_global), _ptr(buf), _ptr(self._grad_full), _ptr(block), self._stream()))
         return self._grad_full, block
 
@@ -359,7 +386,7 @@ class HipEngine(object):
         W = 1 + self.cfg.K + self.cfg.D + 1
         # sorted runs: only where the single-launch forward left them, and while all ids fit the merge kernel's LDS
         runs_ok = n_runs > 0 and rows_all.dim() == 1 and (rows_all.numel() // (W + 2)) * 4 <= 150 * 1024 and \
-            bool(self.lib.cffm_dp_runs_ok(C.byref(self.shape), int(rows_all.numel() // (W + 2) // n_runs // self.cfg.F)))
+            bool(self.lib.cffm_dp_runs_ok(self._s, int(rows_all.numel() // (W + 2) // n_runs // self.cfg.F)))
         if n_runs > 0 and not runs_ok:
             # the blocks carry no sorted runs (shape outside the single-launch forward): strip the key areas
             m = rows_all.numel() // (W + 2) // n_runs
@@ -368,7 +395,7 @@ class HipEngine(object):
         n_rows = rows_all.numel() // (W + 2) if n_runs > 0 else rows_all.shape[0]
         B_ws = max(1, -(-n_rows // self.cfg.F))       # an owner that received no rows still applies the dense update
         buf, _ = self.workspace(B_ws)
-        hip.check(self.lib.cffm_dp_apply(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+        hip.check(self.lib.cffm_dp_apply(self._s, self._t, self._ta,
                                          _ptr(self.theta), _ptr(self.theta_acc), _ptr(grad_full), int(B_global),
                                          _ptr(rows_all), int(n_rows), _ptr(buf), int(B_ws), _ptr(self.loss_buf),
                                          int(n_runs), self._stream()))
@@ -380,7 +407,7 @@ class HipEngine(object):
         collective and the merge + segment walk of the gathered rows: measured 133 vs 152 us per step at world size 1,
         frappe), and the single-launch forward (which leaves the sorted keys the scatter needs) covers this shape."""
         W = self.cfg.K + self.cfg.D + 1
-        return bool(self.lib.cffm_dp_runs_ok(C.byref(self.shape), int(B))) and \
+        return bool(self.lib.cffm_dp_runs_ok(self._s, int(B))) and \
             self.cfg.M * W <= 2 * world * B * self.cfg.F * (W + 3) and self.cfg.optimizer == 'AdagradOptimizer'
 
     def dp_local_dense(self, ids, y, B, B_global):
@@ -388,14 +415,14 @@ class HipEngine(object):
         buf, _ = self.workspace(B)
         flat = self._ws.get('flat')
         if flat is None:
-            flat = torch.zeros(int(self.lib.cffm_dp_dense_floats(C.byref(self.shape))), dtype=torch.float32, device=self.device)
+            flat = torch.zeros(int(self.lib.cffm_dp_dense_floats(self._s)), dtype=torch.float32, device=self.device)
             self._ws['flat'] = flat
-        hip.check(self.lib.cffm_dp_local_dense(C.byref(self.shape), C.byref(self.tables), _ptr(self.theta), _ptr(ids), _ptr(y),
+        hip.check(self.lib.cffm_dp_local_dense(self._s, self._t, _ptr(self.theta), _ptr(ids), _ptr(y),
                                                int(B), int(B_global), _ptr(buf), _ptr(flat), self._stream()))
         return flat
 
     def dp_apply_dense(self, flat_sum, B_global):
-        hip.check(self.lib.cffm_dp_apply_dense(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+        hip.check(self.lib.cffm_dp_apply_dense(self._s, self._t, self._ta,
                                                _ptr(self.theta), _ptr(self.theta_acc), _ptr(flat_sum), int(B_global),
                                                _ptr(self.loss_buf), self._stream()))
         return self.loss_buf
@@ -407,7 +434,7 @@ class HipEngine(object):
     def apply_sparse(self, ids, dEi, dEo, dfb, B_ws):
         ids = self._ids(ids.reshape(-1))
         buf, _ = self.workspace(B_ws)
-        hip.check(self.lib.cffm_sparse_adagrad(C.byref(self.shape), C.byref(self.tables), C.byref(self.tables_acc),
+        hip.check(self.lib.cffm_sparse_adagrad(self._s, self._t, self._ta,
                                                _ptr(ids), int(ids.numel()), _ptr(dEi), _ptr(dEo), _ptr(dfb),
                                                _ptr(buf), int(B_ws), self._stream()))
 
@@ -434,6 +461,6 @@ class HipEngine(object):
         Ei = torch.empty((B, F, self.cfg.K), dtype=torch.float32, device=dev) if want_inner else None
         Eo = torch.empty((B, F, self.cfg.D), dtype=torch.float32, device=dev) if want_outer else None
         fb = torch.empty((B, F), dtype=torch.float32, device=dev) if want_bias else None
-        hip.check(self.lib.cffm_gather(C.byref(self.shape), C.byref(self.tables), _ptr(ids), B, _ptr(Ei), _ptr(Eo),
+        hip.check(self.lib.cffm_gather(self._s, self._t, _ptr(ids), B, _ptr(Ei), _ptr(Eo),
                                        _ptr(fb), self._stream()))
         return Ei, Eo, fb

@@ -1,6 +1,15 @@
-"""ctypes binding of libcffm_hip.so (the C ABI declared in include/cffm_hip.h).
+"""Python binding of libcffm_hip.so (the C ABI declared in include/cffm_hip.h).
 
-There is deliberately no fallback: if the library is missing or a call fails this module raises.
+Two equivalent bindings of the same entry points:
+
+* ``fast()``  - the thin pybind11 module ``cffm_amd/lib/_cffm_pybind*.so`` (csrc_host/pybind_module.cpp, built by
+  ``make``): what the engine's per-step calls go through.  Every pointer is passed as a plain integer
+  (``tensor.data_ptr()``, ``ctypes.addressof(struct)``).
+* ``load()``  - ctypes (``PROTOTYPES`` below): used for the layout queries, by the tools and as the documented
+  alternative binding; it accepts the same integer arguments, so ``fast()`` falls back to it when the
+  pybind11 module has not been built.
+
+There is deliberately no CPU fallback: if the library is missing or a call fails this module raises.
 """
 import ctypes as C
 import os
@@ -47,15 +56,15 @@ class Tables(C.Structure):
 
 
 _P = C.c_void_p
-_SH = C.POINTER(Shape)
-_TB = C.POINTER(Tables)
+_SH = C.c_void_p          # const cffm_shape_t*: byref(Shape) or its address as an int
+_TB = C.c_void_p          # const cffm_tables_t*
 
 # name -> (restype, argtypes); every symbol include/cffm_hip.h declares
 PROTOTYPES = {
     'cffm_abi_version': (C.c_int, []),
     'cffm_error_string': (C.c_char_p, [C.c_int]),
-    'cffm_theta_layout': (C.c_int, [_SH, C.POINTER(ThetaLayout)]),
-    'cffm_ws_layout': (C.c_int, [_SH, C.c_int32, C.POINTER(WsLayout)]),
+    'cffm_theta_layout': (C.c_int, [_SH, _P]),
+    'cffm_ws_layout': (C.c_int, [_SH, C.c_int32, _P]),
     'cffm_gather': (C.c_int, [_SH, _TB, _P, C.c_int32, _P, _P, _P, _P]),
     'cffm_inner_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
     'cffm_inner_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
@@ -78,10 +87,15 @@ PROTOTYPES = {
     'cffm_dp_local_dense': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_dp_apply_dense': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, C.c_int64, _P, _P]),
     'cffm_dp_local': (C.c_int, [_SH, _TB, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    'cffm_packed_row_floats': (C.c_int32, [_SH]),
+    'cffm_gather_packed': (C.c_int, [_SH, _TB, _P, C.c_int64, _P, _P]),
+    'cffm_stage_packed': (C.c_int, [_SH, _P, _P, C.c_int64, C.c_int32, _P, _P]),
+    'cffm_pack_rows_dedup': (C.c_int, [_SH, _P, _P, _P, C.c_int32, _P, _P, _P]),
     'cffm_eval_scratch_bytes': (C.c_int64, []),
     'cffm_eval_sums': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
-    'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), _P]),
+    'cffm_probe_read': (C.c_int, [_P, _P, C.c_int64, _P]),
+    'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, _P, _P]),
     'cffm_train_step_opt': (C.c_int, [_SH, _TB, _TB, _TB, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     'cffm_train_step': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
 }
@@ -108,6 +122,32 @@ def load():
         raise RuntimeError('cffm_amd: ABI version mismatch')
     _lib = lib
     return lib
+
+
+_fast = None
+
+
+def fast():
+    """The per-step binding: the pybind11 module when it is built, else the ctypes library (same names, same integer
+    arguments).  ``binding_name()`` says which one is in use."""
+    global _fast
+    if _fast is None:
+        lib = load()                                   # libcffm_hip.so (and through torch, libamdhip64) is in the process
+        try:
+            from .lib import _cffm_pybind as mod
+            if mod.cffm_abi_version() != ABI_VERSION:
+                raise ImportError('stale _cffm_pybind')
+            missing = [n for n in PROTOTYPES if not hasattr(mod, n)]
+            if missing:
+                raise ImportError('_cffm_pybind lacks %s' % missing)
+            _fast = mod
+        except ImportError:
+            _fast = lib
+    return _fast
+
+
+def binding_name():
+    return 'pybind11' if fast() is not _lib else 'ctypes'
 
 
 def check(rc):

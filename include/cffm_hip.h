@@ -206,6 +206,24 @@ int cffm_train_step(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_
                     float *theta, float *theta_acc, float *grad, const int32_t *ids, const float *y,
                     int32_t B, void *ws, float *loss, void *stream);
 
+/* ---- row-sharded tables (cffm_amd/dist.py ShardedStep) -------------------------------------------------
+ * The reference is single-device: these replace nothing in it; they are the device side of the three all-to-alls.
+ * A looked-up row travels as ONE packed record of cffm_packed_row_floats(s) = K + D + 4 floats:
+ * (inner row | outer row | feature_bias, 0, 0, 0), i.e. tf.nn.embedding_lookup x3 (CFFM.py:303, :354, :422) of one id. */
+int32_t cffm_packed_row_floats(const cffm_shape_t *s);
+/* owner side: rows int32 [n] (local row indices) -> out [n][K+D+4] */
+int cffm_gather_packed(const cffm_shape_t *s, const cffm_tables_t *t, const int32_t *rows, int64_t n, float *out, void *stream);
+/* requester side: slot i of the [B,F] batch takes record pos[i] of packed [n_records][K+D+4] (pos == NULL: record i) ->
+ * ws.Ei / ws.Eo / ws.fb, ready for cffm_forward(tab = NULL) */
+int cffm_stage_packed(const cffm_shape_t *s, const float *packed, const int32_t *pos, int64_t n_records, int32_t B, void *ws,
+                      void *stream);
+/* gradient message with the duplicates of one id summed first, in slot order: order int32 [B*F] = slot at sorted position q
+ * (sorted by destination, stable), uniq int32 [B*F] = index of the distinct id at position q (non-decreasing), local_ids
+ * int32 [B*F] = the owner's row of every slot; ws.dEi / ws.dEo / ws.dfb -> out [#distinct][1+K+D+1] = (row bits | dEi |
+ * dEo | dfb), the row format cffm_dp_apply takes */
+int cffm_pack_rows_dedup(const cffm_shape_t *s, const int32_t *local_ids, const int32_t *order, const int32_t *uniq, int32_t B,
+                         void *ws, float *out, void *stream);
+
 /* ---- evaluate() (CFFM.py:583-615) without a device-to-host copy of the predictions ------------------------------- */
 /* clip + metric sums of CFFM.py:607-614 over n rows: p = min(max(pred, lo), hi) with lo/hi = min/max of the split's labels;
  * sums[0] += sum (y - p)^2, sums[1] += sum y, sums[2] += sum y^2, all float64, in a fixed order (bitwise reproducible).
@@ -218,6 +236,8 @@ int cffm_eval_sums(const float *pred, const float *y, int64_t n, float lo, float
 /* ---- peak probes (bench.py prices the kernels against the data-sheet peaks AND these measured ones) ------------- */
 /* float4 streaming copy src -> dst (bytes % 16 == 0): 2*bytes of HBM traffic per launch */
 int cffm_probe_copy(const void *src, void *dst, int64_t bytes, void *stream);
+/* read-only stream of `bytes` (the HBM READ roofline a gather is priced against); sink: >= 2048 floats, practically never written */
+int cffm_probe_read(const void *src, void *sink, int64_t bytes, void *stream);
 /* dependency-free fp32 MFMA loop over the whole chip; *flops receives the flop count of the launch */
 int cffm_probe_mfma(float *out, int32_t iters, int64_t *flops, void *stream);
 

@@ -23,13 +23,24 @@ def lib():
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
     header = open(os.path.join(ROOT, 'include', 'cffm_hip.h')).read()
-    declared = set(re.findall(r'^\s*(?:int|int64_t|const char \*)\s*\*?\s*(cffm_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^\s*(?:int|int32_t|int64_t|const char \*)\s*\*?\s*(cffm_\w+)\s*\(', header, flags=re.M))
     assert len(declared) >= 20
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.cffm_abi_version() == hip.ABI_VERSION == 5
     assert b'bad shape' in lib.cffm_error_string(10001)
+    # the pybind11 layer (north_star's binding) exposes the same entry points and is what the engine calls through
+    fast = hip.fast()
+    assert hip.binding_name() == 'pybind11', 'cffm_amd/lib/_cffm_pybind*.so is not built (make)'
+    for name in declared:
+        assert callable(getattr(fast, name)), name
+    assert fast.cffm_abi_version() == 5 and 'bad shape' in fast.cffm_error_string(10001)
+    sh = hip.make_shape(CFFMConfig(M=10, F=3, K=8, D=8))
+    assert fast.cffm_packed_row_floats(C.addressof(sh)) == lib.cffm_packed_row_floats(C.byref(sh)) == 20
+    tl_a, tl_b = hip.ThetaLayout(), hip.ThetaLayout()
+    assert fast.cffm_theta_layout(C.addressof(sh), C.addressof(tl_a)) == 0 == lib.cffm_theta_layout(C.byref(sh), C.byref(tl_b))
+    assert bytes(tl_a) == bytes(tl_b)
 
 
 def test_theta_layout_matches_reference_variable_sizes(lib):

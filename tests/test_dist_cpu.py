@@ -149,20 +149,28 @@ class ShardedOracleCompute(OracleCompute):
 
     def gather_packed(self, local_rows):
         r = local_rows.numpy().astype(np.int64)
+        pad = np.zeros((r.shape[0], 3))
         return torch.from_numpy(np.concatenate([self.p['inner_embeddings'][r], self.p['outer_embeddings'][r],
-                                                self.p['feature_bias'][r].reshape(-1, 1)], axis=1))
+                                                self.p['feature_bias'][r].reshape(-1, 1), pad], axis=1))
 
-    def forward_rows(self, Ei, Eo, fb, y, B):
+    def stage_packed(self, packed, pos, B):
+        K, D = self.cfg.K, self.cfg.D
+        rec = packed.numpy()[pos.numpy().astype(np.int64)]           # duplicates of an id share one record
+        assert rec.shape == (B * self.cfg.F, K + D + 4) and np.all(rec[:, K + D + 1:] == 0)
+        self._staged = (rec[:, :K].copy(), rec[:, K:K + D].copy(), rec[:, K + D].copy())
+
+    def forward_staged(self, y, B):
+        Ei, Eo, fb = self._staged
         F = self.cfg.F
         q = dict(self.p)                       # the looked-up rows act as a private B*F-row table
-        q['inner_embeddings'], q['outer_embeddings'] = Ei.numpy(), Eo.numpy()
-        q['feature_bias'] = fb.numpy().reshape(-1, 1)
+        q['inner_embeddings'], q['outer_embeddings'] = Ei, Eo
+        q['feature_bias'] = fb.reshape(-1, 1)
         self.X = np.arange(B * F).reshape(B, F)
         self.out, self.cache = orc.forward(q, self.X, self.cfg)
         self._q = q
         self.sc[0] = float(np.sum((y.numpy() - self.out) ** 2))
 
-    def backward_unscaled(self, ids, y, B, Bg):
+    def backward_unscaled(self, ids, y, B, Bg, pack=True):
         p, self.p = self.p, self._q
         try:
             self.X_save = self.X
@@ -170,7 +178,17 @@ class ShardedOracleCompute(OracleCompute):
         finally:
             self.p = p
         rows[:, 0] = ids.reshape(-1).to(torch.float64)          # keyed by the owner's local row
-        return grad, rows
+        self._rows = rows
+        return grad, (rows if pack else None)
+
+    def pack_rows_dedup(self, local_ids, order, uniq, B):
+        rows = self._rows.numpy()
+        o, u = order.numpy().astype(np.int64), uniq.numpy().astype(np.int64)
+        out = np.zeros_like(rows)
+        np.add.at(out, u, rows[o])                                  # duplicates summed before they travel
+        heads = np.r_[True, u[1:] != u[:-1]]
+        out[u[heads], 0] = local_ids.reshape(-1).numpy()[o[heads]]
+        return torch.from_numpy(out)
 
 
 def _case():
@@ -225,6 +243,43 @@ def _sharded_step_worker(rank, world):
     sl = slice(rank * per, rank * per + per)
     loss = step.train_step(torch.from_numpy(X[sl]), torch.from_numpy(y[sl]))
     return float(loss[0]), {k: np.asarray(v) for k, v in comp.p.items()}, {k: np.asarray(v) for k, v in comp.acc.items()}
+
+
+def _sharded_two_steps_worker(rank, world, dedup, ahead):
+    """Two steps on two different batches; with ahead=True the second batch's routing plan is issued during the first
+    step (the per-owner counts reach the host one step early)."""
+    from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
+    cfg, p, X, y = _case()
+    import copy
+    lcfg = copy.copy(cfg)
+    lcfg.M = local_rows_count(cfg.M, rank, world)
+    comp = ShardedOracleCompute(lcfg, shard_params(p, rank, world))
+    step = ShardedStep(comp, dedup=dedup)
+    per = X.shape[0] // world
+    sl = slice(rank * per, rank * per + per)
+    X2 = (X[::-1] * 7 + 3) % cfg.M
+    a, b = torch.from_numpy(X[sl].copy()), torch.from_numpy(X2[sl].copy())
+    l1 = step.train_step(a, torch.from_numpy(y[sl]), next_ids=b if ahead else None)
+    assert (step._ahead is not None) == ahead
+    l2 = step.train_step(b, torch.from_numpy(y[sl]))
+    return (float(l1[0]), float(l2[0])), {k: np.asarray(v) for k, v in comp.p.items()}
+
+
+@pytest.mark.parametrize('dedup,ahead', [(True, True), (False, False)])
+def test_row_sharded_two_steps_dedup_and_plan_ahead(dedup, ahead):
+    world = 2
+    res = _run(_sharded_two_steps_worker, world, dedup, ahead)
+    cfg, p, X, y = _case()
+    X2 = (X[::-1] * 7 + 3) % cfg.M
+    acc = orc.init_accumulators(p)
+    L1, _ = orc.train_step(p, acc, X, y, cfg)
+    L2, _ = orc.train_step(p, acc, X2, y, cfg)
+    for rank in range(world):
+        (l1, l2), got = res[rank]
+        assert abs(l1 - L1) < 1e-12 and abs(l2 - L2) < 1e-10
+        for k, v in got.items():
+            ref = p[k][rank::world] if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias') else p[k]
+            np.testing.assert_allclose(v, ref, rtol=1e-9, atol=1e-11, err_msg='rank %d %s' % (rank, k))
 
 
 @pytest.mark.parametrize('world', [2, 4])

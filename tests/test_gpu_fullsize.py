@@ -166,20 +166,67 @@ def test_cfg4_train_step_at_full_size_by_linearity():
         assert np.all(ga[tname][mask] == np.float32(1e-8))
 
 
-def test_cfg5_share_row_sharded_world1():
-    """One GPU's share of BASELINE.json configs[4]: 10 M features, 32 fields, dim 64, 8192 rows per GPU through
-    ShardedStep (row-sharded tables, the three all-to-alls and the all-reduce over RCCL loopback at world size 1).
-    Forward outputs and per-example row gradients of 4 examples against the oracle (on the table rows those examples
-    touch, read before the step), and the invariants of the owner-side update."""
+@pytest.fixture(scope='module')
+def nccl_world1():
     import torch.distributed as dist
-    from cffm_amd.dist import ShardedStep
-    from cffm_amd.engine import HipEngine
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29541')
     created = not dist.is_initialized()
     if created:
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    try:
+    yield
+    if created:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dedup', [True, False])
+def test_sharded_step_world1_equals_oracle_step(nccl_world1, dedup):
+    """ShardedStep end to end on one GPU (RCCL loopback): distinct-id exchange, packed records, duplicates re-expanded by
+    cffm_stage_packed and summed again by cffm_pack_rows_dedup, against ONE oracle step - heavy duplication (ids drawn
+    from 40 values per column), two steps with the second batch's plan issued one step ahead."""
+    from cffm_amd.dist import ShardedStep
+    from cffm_amd.engine import HipEngine
+    from tests.test_gpu_parity import adagrad_step_slack, make_case, oracle_dense_grads
+    cfg, p32, X, y = make_case('bookx-relu')
+    rng = np.random.default_rng(4)
+    X = rng.integers(0, 40, size=X.shape).astype(np.int32) * 70
+    X2 = rng.integers(0, 40, size=X.shape).astype(np.int32) * 70
+    eng = HipEngine(cfg, params=p32)
+    sh = ShardedStep(eng, dedup=dedup)
+    a, b, yt = torch.from_numpy(X).cuda(), torch.from_numpy(X2).cuda(), torch.from_numpy(y).cuda()
+    l1 = float(sh.train_step(a, yt, next_ids=b).cpu()[0])
+    assert sh._ahead is not None
+    l2 = float(sh.train_step(b, yt).cpu()[0])
+    torch.cuda.synchronize()
+    p64 = to64(p32)
+    acc = orc.init_accumulators(p64)
+    slack = {}
+    Ls = []
+    for Xs in (X, X2):
+        g = oracle_dense_grads(p64, Xs, y, cfg)
+        for k, v in adagrad_step_slack(g, acc, cfg.lr, rel=2e-5).items():
+            slack[k] = slack.get(k, 0.0) + v
+        Ls.append(orc.train_step(p64, acc, Xs, y.astype(np.float64), cfg)[0])
+    assert abs(l1 - Ls[0]) <= 1e-5 * Ls[0] and abs(l2 - Ls[1]) <= 2e-5 * Ls[1]
+    got = eng.export_params()
+    for k, v in got.items():
+        close(v, p64[k].reshape(v.shape), 'sharded world-1 param ' + k, tol=2e-5,
+              extra=None if k not in slack else slack[k].reshape(v.shape))
+    touched = np.zeros(cfg.M, dtype=bool)
+    touched[X.reshape(-1)] = True
+    touched[X2.reshape(-1)] = True
+    for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+        np.testing.assert_array_equal(got[k][~touched], p32[k][~touched])
+
+
+def test_cfg5_share_row_sharded_world1(nccl_world1):
+    """One GPU's share of BASELINE.json configs[4]: 10 M features, 32 fields, dim 64, 8192 rows per GPU through
+    ShardedStep (row-sharded tables, the three all-to-alls and the all-reduce over RCCL loopback at world size 1).
+    Forward outputs and per-example row gradients of 4 examples against the oracle (on the table rows those examples
+    touch, read before the step), and the invariants of the owner-side update."""
+    from cffm_amd.dist import ShardedStep
+    from cffm_amd.engine import HipEngine
+    if True:
         cfg = CFFMConfig(M=10000000, F=32, K=64, D=64, activation='relu')
         B = 8192
         eng = HipEngine(cfg, params='device', seed=2021)
@@ -231,6 +278,3 @@ def test_cfg5_share_row_sharded_world1():
         assert bool((eng.outer_acc[hit] > 1e-8).any(dim=1).all())
         assert bool((eng.outer[hit] != hit_before).any(dim=1).all())
         assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
-    finally:
-        if created:
-            dist.destroy_process_group()

@@ -97,3 +97,49 @@ def test_native_reader_through_synthetic_generator(tmp_path):
     assert py.Train_data['X'] == nat.Train_data['X'] and py.Train_data['Y'] == nat.Train_data['Y']
     X, Y = LoadData.packed(nat.Train_data)
     assert X.shape == (300, 6) and X.max() < nat.features_M
+
+
+def test_binary_cache_round_trip_and_invalidation(tmp_path):
+    """N2: the parsed splits + token arena are cached next to the data, keyed by size and mtime of the three files."""
+    from cffm_amd import synth
+    synth.write_libfm(str(tmp_path), 'syn', M=300, F=5, n_train=200, n_valid=60, n_test=40, seed=3)
+    path = str(tmp_path) + '/'
+
+    def load(**kw):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            d = LoadData(path, 'syn', 'square_loss', native=True, **kw)
+        return d, buf.getvalue()
+    a, out_a = load()
+    assert not a.cache_hit and os.path.exists(path + 'syn/.syn.cffm_cache.npz')
+    b, out_b = load()
+    assert b.cache_hit and out_a == out_b                                   # same console prints from the cache
+    assert b.features_M == a.features_M and b.features == a.features
+    for x, z in ((a.Train_data, b.Train_data), (a.Validation_data, b.Validation_data), (a.Test_data, b.Test_data)):
+        assert x['X'] == z['X'] and x['Y'] == z['Y']
+    c, _ = load(cache=False)
+    assert not c.cache_hit and c.Train_data['X'] == a.Train_data['X']
+    # a changed file invalidates the cache (size/mtime key), and the new content is what comes back
+    with open(path + 'syn/syn.test.libfm', 'a') as fh:
+        fh.write('1 999999:1 1:1 2:1 3:1 4:1\n')
+    d, _ = load()
+    assert not d.cache_hit and len(d.Test_data['Y']) == len(a.Test_data['Y']) + 1 and '999999:1' in d.features
+    # log_loss labels come out of the same cache
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        e = LoadData(path, 'syn', 'log_loss', native=True)
+    assert e.cache_hit and set(e.Train_data['Y']) <= {0.0, 1.0}
+
+
+def test_lazy_split_behaves_like_the_reference_dict():
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = LoadData(PATH, 'frappe', 'square_loss', native=True)
+    s = d.Train_data
+    assert isinstance(s, dict) and 'X' in s and 'Y' in s and len(s) == 2 and sorted(s.keys()) == ['X', 'Y']
+    X, Y = LoadData.packed(s)                                 # no lists built yet
+    assert not dict.__contains__(s, 'X')
+    assert s['X'] == X.tolist() and s['Y'] == Y.astype(np.float64).tolist()
+    s['X'] = [r[::-1] for r in s['X']]                        # re-binding (CFFM.py:183 does it every epoch)
+    X2, _ = LoadData.packed(s)
+    assert X2.tolist() == [r[::-1] for r in X.tolist()]
+    assert d.truncate_features() == 10

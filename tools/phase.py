@@ -13,11 +13,11 @@ for i in range(20):
     eng.train_step(X[i % 8], y[i % 8])
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
-eng.lib.cffm_debug_phase_times.argtypes = [C.c_void_p]
+hip.load().cffm_debug_phase_times.argtypes = [C.c_void_p]
 rows = []
 for i in range(10):
     eng.train_step(X[i % 8], y[i % 8]); torch.cuda.synchronize()
-    eng.lib.cffm_debug_phase_times(buf)
+    hip.load().cffm_debug_phase_times(buf)
     t = np.array(list(buf), dtype=np.int64)[:8]
     rows.append(np.diff(t) * 10)       # ns
     t2 = np.array(list(buf), dtype=np.int64)[8:14]
