@@ -107,8 +107,12 @@ class CFFM(object):
         if optimizer_type not in ('AdagradOptimizer', 'AdamOptimizer', 'GradientDescentOptimizer', 'MomentumOptimizer'):
             # the reference leaves self.optimizer unset for any other string and dies at the first sess.run (CFFM.py:517-529)
             raise ValueError('unknown optimizer %r' % (optimizer_type,))
-        if optimizer_type != 'AdagradOptimizer' and lamda_bilinear > 0:
-            raise NotImplementedError('lamda > 0 is built for AdagradOptimizer only (the reference default)')
+        if loss_type == 'square_loss' and lamda_bilinear > 0:
+            # create_loss regularises self.weights['inner_embeddings'] and ['outer_embeddings'] (CFFM.py:489-491), which
+            # only exist for an enabled branch (CFFM.py:255, :262): the reference dies with this KeyError at graph build
+            for flag, name in ((inner_conv, 'inner_embeddings'), (outer_conv, 'outer_embeddings')):
+                if flag != 1:
+                    raise KeyError(name)
         if tensorboard > 0:
             logging.warning('--tensorboard is accepted and ignored (it crashes the reference, CFFM.py:194-196)')
         self.config = CFFMConfig(M=features_M, F=num_field, K=inner_dims, D=outer_dims, activation=activation_function,

@@ -203,7 +203,6 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
     int rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr,
                            (hipStream_t)stream, true);
     if (rc || B <= 0) return rc;
-    if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
     cffm_ws_layout_t wl; cffm_theta_layout_t tl;
     cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
     char* w = (char*)ws;
@@ -211,7 +210,8 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
         hipError_t e = hipMemcpyAsync(grad + tl.n, w + wl.scalars, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
         return e == hipSuccess ? 0 : (int)e;
     }
-    return cffm_pack_rows(s, ids, B, (const float*)(w + wl.dEi), (const float*)(w + wl.dEo), (const float*)(w + wl.dfb),
+    return cffm_pack_rows(s, ids, B, s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
+                          s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
 }
 
@@ -232,9 +232,8 @@ extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, co
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
-    if (!s->inner_conv || !s->outer_conv || !y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)
-        return CFFM_ERR_UNSUPPORTED;
-    const bool run = cffm_fwd_all_ok(s, B);          // the single-launch forward also leaves this rank's keys sorted
+    if (!y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2) return CFFM_ERR_UNSUPPORTED;
+    const bool run = cffm_fwd_all_ok(s, B);          // false for a disabled branch: plain forward, no sorted run          // the single-launch forward also leaves this rank's keys sorted
     const bool later = run && defer_rank(s, B);
     if (run) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later);
     else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st);
@@ -276,6 +275,8 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
     if (s->loss == CFFM_LOSS_SQUARE_L2) {       // regularised square loss: dense table gradients and updates
+        // the reference cannot build this graph with a disabled branch either: create_loss reads self.weights['inner_embeddings']
+        // and ['outer_embeddings'] (CFFM.py:489-491), which initialize_variables only creates for an enabled branch (:255, :262)
         if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
         if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st))) return rc;
         if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
@@ -306,7 +307,7 @@ extern "C" int cffm_train_step_opt(const cffm_shape_t* s, const cffm_tables_t* t
     if (s->optimizer == CFFM_OPT_ADAGRAD)
         return cffm_train_step(s, tab, tab_state1, theta, theta_state1, grad, ids, y, B, ws, loss, stream);
     if (B <= 0) return 0;
-    if (s->loss == CFFM_LOSS_SQUARE_L2 || !s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
+    if (s->loss == CFFM_LOSS_SQUARE_L2 && (!s->inner_conv || !s->outer_conv)) return CFFM_ERR_UNSUPPORTED;   // as in cffm_train_step
     hipStream_t st = (hipStream_t)stream;
     if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st))) return rc;
     // gradients only (no fused Adagrad); the loss is written by head_bwd

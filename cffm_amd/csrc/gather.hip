@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const int32_t* __restric
         const int c = (int)(i - slot * W);
         float v;
         if (c == 0) v = __int_as_float(ids[slot]);
-        else if (c <= K) v = dEi[slot * K + (c - 1)];
-        else if (c <= K + D) v = dEo[slot * D + (c - 1 - K)];
+        else if (c <= K) v = dEi ? dEi[slot * K + (c - 1)] : 0.f;       // disabled branch: zeros
+        else if (c <= K + D) v = dEo ? dEo[slot * D + (c - 1 - K)] : 0.f;
         else v = dfb[slot];
         rows[i] = v;
     }

@@ -187,8 +187,8 @@ __device__ __forceinline__ void pack_rows_body(int bid, int nblk, const PackArgs
         const int c = (int)(i - slot * W);
         float v;
         if (c == 0) v = __int_as_float(a.ids[slot]);
-        else if (c <= a.K) v = a.dEi[slot * a.K + (c - 1)];
-        else if (c <= a.K + a.D) v = a.dEo[slot * a.D + (c - 1 - a.K)];
+        else if (c <= a.K) v = a.dEi ? a.dEi[slot * a.K + (c - 1)] : 0.f;           // disabled branch: its columns travel as zeros
+        else if (c <= a.K + a.D) v = a.dEo ? a.dEo[slot * a.D + (c - 1 - a.K)] : 0.f;
         else v = a.dfb[slot];
         a.rows[i] = v;
     }
@@ -213,7 +213,8 @@ int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws,
     make_slab_plan(s, B, tl, &sp);
     PackArgs pa;
     pa.ids = ids; pa.n_slots = (int64_t)B * s->F; pa.K = s->K; pa.D = s->D; pa.B = B;
-    pa.dEi = (const float*)(w + wl.dEi); pa.dEo = (const float*)(w + wl.dEo); pa.dfb = (const float*)(w + wl.dfb);
+    pa.dEi = s->inner_conv ? (const float*)(w + wl.dEi) : nullptr; pa.dEo = s->outer_conv ? (const float*)(w + wl.dEo) : nullptr;
+    pa.dfb = (const float*)(w + wl.dfb);
     pa.sqerr = (const float*)(w + wl.sqerr); pa.sum_dst = grad + tl.n; pa.rows = rows; pa.scalars = (float*)(w + wl.scalars);
     // n_slots * W floats: W = K + D + 2 is even for the float4-aligned K, D this library accepts, so the run is 8-byte aligned
     pa.keys_sorted = with_run ? (const unsigned long long*)(w + wl.sort_vals) : nullptr;
@@ -448,12 +449,14 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
                              int64_t n_rows, void* ws, int32_t B_ws, float* loss_out, int32_t n_runs, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
-    if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     cffm_theta_layout_t tl;
     cffm_theta_layout(s, &tl);
     LateScale ls = {grad_sum + tl.n, 1.f / (float)B_global, s->loss == CFFM_LOSS_SQUARE_RMSE ? 1 : 0};
     const int64_t W = 1 + s->K + s->D + 1;
+    // a disabled branch (CFFM.py:301, :348) has no table: its columns of the rows are zeros and are not applied
+    const float* rEi = s->inner_conv ? rows + 1 : nullptr;
+    const float* rEo = s->outer_conv ? rows + 1 + s->K : nullptr;
     const int n_dense = (int)((tl.n + 255) / 256);
     if (n_runs > 0) {
         // sorted runs (one per rank, from cffm_dp_local): merge by rank, rows addressed block-wise
@@ -474,7 +477,7 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
                            grad_sum, (int64_t)tl.n, s->lr, ls, loss_out, n_dense, ma);
         CFFM_CHECK_LAUNCH();
         SparseArgs a;
-        fill_sparse_args(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws, B_ws, ls, &a);
+        fill_sparse_args(s, tab, acc, n_rows, rEi, W, rEo, W, rows + 1 + s->K + s->D, W, ws, B_ws, ls, &a);
         a.run_len = m; a.run_stride = ma.block_floats; a.inv_run_len = 1.f / (float)m;
         hipLaunchKernelGGL(sparse_adagrad_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, a);
         CFFM_CHECK_LAUNCH();
@@ -496,8 +499,7 @@ extern "C" int cffm_dp_apply(const cffm_shape_t* s, const cffm_tables_t* tab, co
         rc = cffm_sort_keys_impl(s, (const int32_t*)rows, n_rows, ws, B_ws, false, st, W);
         if (rc) return rc;
     }
-    return cffm_sparse_apply_strided(s, tab, acc, n_rows, rows + 1, W, rows + 1 + s->K, W, rows + 1 + s->K + s->D, W, ws,
-                                     B_ws, ls, st);
+    return cffm_sparse_apply_strided(s, tab, acc, n_rows, rEi, W, rEo, W, rows + 1 + s->K + s->D, W, ws, B_ws, ls, st);
 }
 
 // ---- data-parallel step for SMALL vocabularies: the tables' gradients travel as one dense buffer --------------------
@@ -714,12 +716,13 @@ __device__ __forceinline__ void opt_update(float& w, float* s1, float* s2, float
     }
 }
 
+// lam != 0: the l2_regularizer term of the regularised square loss (CFFM.py:489-491), g = grad + lam * w
 __global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, float* __restrict__ s1, float* __restrict__ s2,
-                                                        const float* __restrict__ grad, int64_t n, OptConst c) {
+                                                        const float* __restrict__ grad, int64_t n, OptConst c, float lam) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float wv = w[i];
-    opt_update(wv, s1 ? s1 + i : nullptr, s2 ? s2 + i : nullptr, grad ? grad[i] : 0.f, c);
+    opt_update(wv, s1 ? s1 + i : nullptr, s2 ? s2 + i : nullptr, (grad ? grad[i] : 0.f) + lam * wv, c);
     w[i] = wv;
 }
 
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const unsigned long lon
                                                          const float* __restrict__ dEi, const float* __restrict__ dEo,
                                                          const float* __restrict__ dfb, cffm_tables_t tab, cffm_tables_t st1,
                                                          float* __restrict__ Gi, float* __restrict__ Go, float* __restrict__ Gfb,
-                                                         OptConst c) {
+                                                         OptConst c, int dense_tables) {
     const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pos >= n) return;
@@ -740,6 +743,8 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const unsigned long lon
     for (int c0 = 0; c0 < W; c0 += 64) {
         const int col = c0 + lane;
         if (col >= W) continue;
+        // a disabled branch (CFFM.py:301, :348) has no table variable: nothing to update
+        if ((col < K && dEi == nullptr) || (col >= K && col < K + D && dEo == nullptr)) continue;
         float g = 0.f;
         for (int64_t q = pos; q < n; ++q) {
             const unsigned long long kq = keys[q];
@@ -749,7 +754,8 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const unsigned long lon
         }
         const int64_t off = col < K ? (int64_t)id * K + col : (col < K + D ? (int64_t)id * D + (col - K) : (int64_t)id);
         float* wt = col < K ? tab.inner_emb : (col < K + D ? tab.outer_emb : tab.feat_bias);
-        if (c.opt == CFFM_OPT_ADAM) {
+        // dense gradient of a table (Adam's non-lazy sparse apply; the regularised loss): the summed rows go to G*
+        if (c.opt == CFFM_OPT_ADAM || (dense_tables && col < K + D)) {
             (col < K ? Gi : (col < K + D ? Go : Gfb))[off] = g;
         } else {
             float* s1 = c.opt == CFFM_OPT_MOMENTUM ? (col < K ? st1.inner_emb : (col < K + D ? st1.outer_emb : st1.feat_bias)) + off : nullptr;
@@ -770,11 +776,15 @@ int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_t
     c.opt = s->optimizer; c.lr = s->lr; c.b1 = 0.9f; c.b2 = 0.999f; c.omb1 = (float)(1.0 - 0.9); c.omb2 = (float)(1.0 - 0.999); c.eps = 1e-8f; c.mom = 0.95f;
     c.lr_t = (float)((double)s->lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step)));
     hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((tl.n + 255) / 256)), dim3(256), 0, st, theta, th1, th2, grad,
-                       (int64_t)tl.n, c);
+                       (int64_t)tl.n, c, 0.f);
     CFFM_CHECK_LAUNCH();
+    // regularised square loss (CFFM.py:489-491): the l2 terms make the gradients of the two embedding tables dense for
+    // every optimizer (IndexedSlices + dense aggregates to dense); feature_bias stays sparse (Adam: non-lazy, all rows)
+    const bool l2 = s->loss == CFFM_LOSS_SQUARE_L2;
+    const bool adam = c.opt == CFFM_OPT_ADAM;
     float *Gi = nullptr, *Go = nullptr, *Gfb = nullptr;
     const int64_t ni = (int64_t)s->M * s->K, no = (int64_t)s->M * s->D, nf = s->M;
-    if (c.opt == CFFM_OPT_ADAM) {
+    if (adam || l2) {
         Gi = (float*)(w + wl.Gi); Go = (float*)(w + wl.Go); Gfb = (float*)(w + wl.Gfb);
         hipError_t e = hipMemsetAsync(Gi, 0, (size_t)(wl.Gfb + nf * 4 - wl.Gi), st);     // the three buffers are contiguous
         if (e != hipSuccess) return (int)e;
@@ -782,17 +792,22 @@ int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_t
     int rc = cffm_sort_keys_impl(s, ids, n_rows, ws, B_ws, true, st);
     if (rc) return rc;
     cffm_tables_t t1 = st1 ? *st1 : cffm_tables_t{nullptr, nullptr, nullptr};
+    cffm_tables_t t2 = st2 ? *st2 : cffm_tables_t{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(sparse_opt_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st,
-                       (const unsigned long long*)(w + wl.sort_vals), n_rows, s->M, s->K, s->D, (const float*)(w + wl.dEi),
-                       (const float*)(w + wl.dEo), (const float*)(w + wl.dfb), *tab, t1, Gi, Go, Gfb, c);
+                       (const unsigned long long*)(w + wl.sort_vals), n_rows, s->M, s->K, s->D,
+                       s->inner_conv ? (const float*)(w + wl.dEi) : nullptr, s->outer_conv ? (const float*)(w + wl.dEo) : nullptr,
+                       (const float*)(w + wl.dfb), *tab, t1, Gi, Go, Gfb, c, l2 ? 1 : 0);
     CFFM_CHECK_LAUNCH();
-    if (c.opt == CFFM_OPT_ADAM) {
-        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, st, tab->inner_emb, st1->inner_emb,
-                           st2->inner_emb, (const float*)Gi, ni, c);
-        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, tab->outer_emb, st1->outer_emb,
-                           st2->outer_emb, (const float*)Go, no, c);
-        hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, tab->feat_bias, st1->feat_bias,
-                           st2->feat_bias, (const float*)Gfb, nf, c);
+    if (adam || l2) {      // dense sweeps; a disabled branch has no table variable and is left alone
+        if (s->inner_conv)
+            hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, st, tab->inner_emb, t1.inner_emb,
+                               t2.inner_emb, (const float*)Gi, ni, c, l2 ? s->lamda : 0.f);
+        if (s->outer_conv)
+            hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, tab->outer_emb, t1.outer_emb,
+                               t2.outer_emb, (const float*)Go, no, c, l2 ? s->lamda_att : 0.f);    // quirk Q13: lamda_att scales the outer table
+        if (adam)
+            hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, tab->feat_bias, t1.feat_bias,
+                               t2.feat_bias, (const float*)Gfb, nf, c, 0.f);
         CFFM_CHECK_LAUNCH();
     }
     return 0;

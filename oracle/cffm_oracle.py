@@ -413,6 +413,14 @@ def apply_optimizer(p, st, g, X, cfg):
     ids = np.asarray(X).reshape(-1)
     dense = {k: np.asarray(v).reshape(np.shape(p[k])) for k, v in g.items() if not k.startswith('d_') and not k.startswith('_')}
     tabs = {'inner_embeddings': g.get('d_inner_rows'), 'outer_embeddings': g.get('d_outer_rows'), 'feature_bias': g['d_bias_rows']}
+    lam = getattr(cfg, 'lamda_bilinear', 0.0)
+    if cfg.loss_type == 'square_loss' and lam > 0:
+        # CFFM.py:489-491: the l2_regularizer terms add lamda * w (outer table: lamda_att * w, quirk Q13) to the table
+        # gradients; IndexedSlices + dense aggregates to a DENSE gradient, so every optimizer of :517-529 treats the two
+        # embedding tables as dense variables (feature_bias keeps its IndexedSlices gradient)
+        for k, scale in (('inner_embeddings', lam), ('outer_embeddings', cfg.lamda_att)):
+            dense[k] = _dense_table_grad(p, k, ids, tabs[k]) + scale * p[k]
+            tabs[k] = None
     if opt == 'AdamOptimizer':
         st['t'] += 1
         b1, b2, eps, t = 0.9, 0.999, 1e-8, st['t']

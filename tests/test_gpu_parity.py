@@ -11,8 +11,9 @@ from oracle import cffm_oracle as orc
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-REL_FLOOR = 1e-3          # elements above REL_FLOOR * max|ref| must also be within REL_TOL relative (an fp32 sum carries
-                          # ~1e-7 * max of absolute rounding error, i.e. 1e-3 relative on an element of 1e-4 * max)
+REL_FLOOR = 1e-2          # elements above REL_FLOOR * max|ref| must also be within REL_TOL relative.  Consistent with tier 1:
+                          # rms <= max, so tol * (|ref| + rms) <= 1e-5 * 101 |ref| ~ 1e-3 |ref| for |ref| >= 1e-2 max; the tier
+                          # therefore binds exactly the <= 1 % of elements tier 1 lets through
 REL_TOL = 1e-3
 WORST = {}                # name -> worst (|err| / bound) seen, printed at the end of the session (see conftest)
 
@@ -22,7 +23,7 @@ def close(got, ref, name, tol=TOL, ignore=None, extra=None):
 
       tier 1   at least 99 % of the elements within B
       tier 2   EVERY element within 4 * B
-      tier 3   every element above 1e-3 * max|ref| within 1e-3 relative
+      tier 3   every element above 1e-2 * max|ref| within 1e-3 relative
 
     An fp32 sum of n terms carries an absolute error that scales with the magnitude of its terms, i.e. with the typical
     size of the tensor (its rms), not with the element itself - hence |ref| + rms, NOT tol * max|ref| (which would let
@@ -537,8 +538,9 @@ def test_full_size_configs(name):
     assert np.isfinite(eng.predict(ids[:64]).cpu().numpy()).all()
 
 
-@pytest.mark.parametrize('route', ['runs', 'rows', 'dense'])
-def test_data_parallel_halves_on_one_gpu(route):
+@pytest.mark.parametrize('route,case', [('runs', 'bookx-relu'), ('rows', 'bookx-relu'), ('dense', 'bookx-relu'),
+                                        ('rows', 'no-inner'), ('runs', 'no-outer'), ('rows', 'fm-only-nolinatt')])
+def test_data_parallel_halves_on_one_gpu(route, case):
     """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run the local half
     of the step on the two halves of a batch, the test plays the role of the two collectives (sum of the flat gradient
     buffers, concatenation of what would be all-gathered), and cffm_dp_apply on each replica must reproduce one oracle
@@ -547,7 +549,9 @@ def test_data_parallel_halves_on_one_gpu(route):
     route 'rows': cffm_forward + cffm_backward_unscaled rows in any order (sorted inside cffm_dp_apply);
     route 'dense': cffm_dp_local_dense buffers (dense gradients + dense image of the table gradients), ONE sum, then
     cffm_dp_apply_dense."""
-    cfg, p32, X, y = make_case('bookx-relu')
+    cfg, p32, X, y = make_case(case)
+    if X.shape[0] % 2:
+        X, y = X[:-1], y[:-1]
     B = X.shape[0]
     h = B // 2
     engines = [engine_for(cfg, p32), engine_for(cfg, p32)]
@@ -673,7 +677,7 @@ def test_regularised_square_loss_step():
 
 
 @pytest.mark.parametrize('opt', ['GradientDescentOptimizer', 'MomentumOptimizer', 'AdamOptimizer'])
-@pytest.mark.parametrize('name', ['bookx-relu', 'frappe-selu'])
+@pytest.mark.parametrize('name', ['bookx-relu', 'frappe-selu', 'no-inner', 'no-outer'])
 def test_other_optimizers(name, opt):
     """cffm_train_step_opt: the other create_optimizer branches (CFFM.py:519-529) against the oracle.  Step 1 is held
     to the gradient tolerance propagated through the update rule (linear for SGD/Momentum; Adam's first step is
@@ -687,7 +691,7 @@ def test_other_optimizers(name, opt):
     Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
     eng.forward(Xd, yd)
     torch.cuda.synchronize()
-    hook = lambda cache: adopt_device_kinks(cfg, eng, B, cache)
+    hook = (lambda cache: adopt_device_kinks(cfg, eng, B, cache)) if cfg.outer_conv else None
     grads = oracle_dense_grads(p64, X, y, cfg, hook)
     st = orc.init_opt_state(p64, opt)
     L, _ = orc.train_step_opt(p64, st, X, y.astype(np.float64), cfg, cache_hook=hook)
@@ -710,13 +714,20 @@ def test_other_optimizers(name, opt):
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
     slots = eng.export_accumulators()
     ref_slot = st['m'] if opt == 'AdamOptimizer' else st.get('acc')
+    live = [k for k in ('inner_embeddings', 'dense_kernel') if cfg.inner_conv] + \
+           [k for k in ('outer_embeddings', 'dense_1_kernel', 'outer_layer_conv_weight_0') if cfg.outer_conv] + ['feature_bias']
     if ref_slot is not None:
-        for k in ('inner_embeddings', 'outer_embeddings', 'dense_1_kernel', 'outer_layer_conv_weight_0'):
+        for k in live:
             close(slots[k], ref_slot[k].reshape(slots[k].shape), 'slot ' + k, tol=2e-5)
     if opt == 'AdamOptimizer':
         v2 = eng.export_second_moments()
-        for k in ('outer_embeddings', 'dense_1_kernel'):
+        for k in live:
             close(v2[k], st['v'][k].reshape(v2[k].shape), 'v ' + k, tol=4e-5)
+    # a disabled branch has no variables in the reference graph: its table and slots are exactly as they were
+    for flag, k in ((cfg.inner_conv, 'inner_embeddings'), (cfg.outer_conv, 'outer_embeddings')):
+        if not flag:
+            np.testing.assert_array_equal(got[k], p32[k])
+            assert np.all(slots[k] == 0)
 
     # ---- second step on other ids
     rng = np.random.default_rng(21)
@@ -733,7 +744,9 @@ def test_other_optimizers(name, opt):
     for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
         np.testing.assert_array_equal(got[k][never], p32[k][never])
         moved = got[k][only1] != before[k][only1]
-        if opt == 'AdamOptimizer':
+        if (k == 'inner_embeddings' and not cfg.inner_conv) or (k == 'outer_embeddings' and not cfg.outer_conv):
+            assert not (got[k] != p32[k]).any(), k
+        elif opt == 'AdamOptimizer':
             assert moved.mean() > 0.9, k                      # m != 0 keeps pushing the row
         else:
             assert not moved.any(), k
@@ -745,6 +758,64 @@ def test_other_optimizers(name, opt):
         ok = err <= 1e-3 * max(np.abs(d_ref).max(), 1e-30) + 4e-7 * np.abs(v)
         # Adam's smoothed sign flips on gradients within rounding of 0: allow a vanishing fraction of such elements
         assert ok.mean() > (0.999 if opt == 'AdamOptimizer' else 0.99999), (k, float(ok.mean()), float(err.max()))
+
+
+@pytest.mark.parametrize('opt', ['GradientDescentOptimizer', 'MomentumOptimizer', 'AdamOptimizer'])
+def test_regularised_square_loss_with_other_optimizers(opt):
+    """--lamda > 0 with the other create_optimizer branches (CFFM.py:489-491 + :519-529): the two embedding tables get a
+    dense gradient scatter(row grads) + lamda * w (outer table: lamda_att, Q13) under every optimizer; feature_bias
+    keeps its sparse gradient.  Two steps against the oracle."""
+    cfg, p32, X, y = make_case('bookx-relu')
+    cfg.lamda_bilinear = 0.02
+    cfg.optimizer, cfg.lr = opt, (0.01 if opt == 'AdamOptimizer' else 1e-4)
+    eng = engine_for(cfg, p32)
+    p64 = to64(p32)
+    B = X.shape[0]
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    eng.forward(Xd, yd)
+    torch.cuda.synchronize()
+    hook = lambda cache: adopt_device_kinks(cfg, eng, B, cache)
+    grads = oracle_dense_grads(p64, X, y, cfg, hook)
+    for k, scale in (('inner_embeddings', cfg.lamda_bilinear), ('outer_embeddings', cfg.lamda_att)):
+        grads[k] = grads[k] + scale * p64[k]
+    st = orc.init_opt_state(p64, opt)
+    orc.train_step_opt(p64, st, X, y.astype(np.float64), cfg, cache_hook=hook)
+    eng.train_step(Xd, yd)
+    torch.cuda.synchronize()
+    got = eng.export_params()
+    e1 = 1e-8 / np.sqrt(0.001)
+    for k, v in got.items():
+        extra = None
+        if k in grads:
+            gk = grads[k].reshape(v.shape)
+            dg = 1e-5 * (np.abs(gk) + max(float(np.sqrt(np.mean(gk * gk))), 1e-30))
+            if opt == 'AdamOptimizer':
+                u = lambda t: cfg.lr * t / (np.abs(t) + e1)
+                extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk))) + 1e-5 * cfg.lr
+            else:
+                extra = cfg.lr * dg
+        close(v, p64[k].reshape(v.shape), 'L2 %s param %s' % (opt, k), tol=2e-5, extra=extra)
+    # every row of both tables moved (dense gradient), rows of feature_bias nobody looked up did not (SGD / Momentum)
+    assert (got['inner_embeddings'] != p32['inner_embeddings']).mean() > 0.99
+    assert (got['outer_embeddings'] != p32['outer_embeddings']).mean() > 0.99
+    touched = np.zeros(cfg.M, dtype=bool)
+    touched[X.reshape(-1)] = True
+    if opt != 'AdamOptimizer':
+        np.testing.assert_array_equal(got['feature_bias'][~touched], p32['feature_bias'][~touched])
+    # second step: the slot state (momentum / Adam moments over ALL rows) carried over
+    before = got
+    p1 = {k: np.array(v) for k, v in p64.items()}
+    rng = np.random.default_rng(5)
+    X2 = rng.integers(0, cfg.M, size=X.shape).astype(np.int32)
+    orc.train_step_opt(p64, st, X2, y.astype(np.float64), cfg)
+    eng.train_step(torch.from_numpy(X2).cuda(), yd)
+    torch.cuda.synchronize()
+    got = eng.export_params()
+    for k, v in got.items():
+        d_dev = v.astype(np.float64) - before[k].astype(np.float64)
+        d_ref = p64[k].reshape(v.shape) - p1[k].reshape(v.shape)
+        ok = np.abs(d_dev - d_ref) <= 1e-3 * max(np.abs(d_ref).max(), 1e-30) + 4e-7 * np.abs(v)
+        assert ok.mean() > (0.999 if opt == 'AdamOptimizer' else 0.99999), (k, float(ok.mean()))
 
 
 def test_row_sharded_halves_on_one_gpu():
