@@ -432,10 +432,14 @@ struct WgradArgs {
     int B, lgSo, P, Pp, F, D, act, qblocks;
 };
 
-template <int NT, bool GEN>
+// RI row tiles per wavefront: the workgroup's output tile is (64*RI) x (16*NT).  RI = 2 halves the dC traffic per MFMA
+// (a B fragment read from LDS feeds two row tiles) - the layers >= 1 of the wide shapes run it; RI = 1 keeps 4*Pp/64 exact
+// for every Pp and is what GEN (direct layer 0) uses.
+template <int NT, bool GEN, int RI = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-    constexpr int BI = 64, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = WG_KM;
+    constexpr int BI = 64 * RI, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = WG_KM;
     constexpr int NB = KM * BQ / 256, NA = KM * BI / 4 / 256;     // per-thread B' floats / A' float4s per step
+    static_assert(!GEN || RI == 1, "the generated layer-0 operand is built for one row tile per wavefront");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);                       // [KM][LDB]
     float* As = Bs + KM * LDB;                                        // [KM][LDA]      (!GEN)
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int64_t s_lo = slab * cps, s_hi = min(nsteps, s_lo + cps);
     const int n_ex = GEN ? (KM > S2 ? KM / S2 : 1) : 0;
 
-    // the (tap, p) this lane's A' row belongs to
+    // the (tap, p) this lane's A' row belongs to (GEN only: RI == 1)
     const int irow = i0 + wave * 16 + r;
     const int tapA = fast_div(irow, invPp), pA = irow - tapA * Pp, dhA = tapA >> 1, dwA = tapA & 1;
     int fi = 0, fj = 0;
@@ -463,17 +467,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         const uint32_t ij = lut[pA];
         fi = ij & 0xffff; fj = ij >> 16;
     }
-    // staging geometry of this thread (fixed over the steps)
+    // staging geometry of this thread (fixed over the steps): BI/4 16-byte pieces per A' row
     int a_tap[NA], a_p[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int ii = i0 + 4 * ((tid + 256 * i) % 16);
-        a_tap[i] = fast_div(ii, invPp);
+        const int ii = i0 + 4 * ((tid + 256 * i) % (BI / 4));
+        a_tap[i] = fast_div(ii, invPp);                          // 4 for the rows of a last, partial tile beyond 4*Pp: zeros
         a_p[i] = ii - a_tap[i] * Pp;
     }
-    f32x4 acc[NT];
+    f32x4 acc[RI][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ri][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     int cur_b = -1;
     float breg[NB];
@@ -490,9 +496,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         if (!GEN) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int64_t m = mbase + (tid + 256 * i) / 16;
+                const int64_t m = mbase + (tid + 256 * i) / (BI / 4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.Mtot) {
+                if (m < a.Mtot && a_tap[i] < 4) {
                     const RowPos rp = row_pos(m, a.lgSo);
                     const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y + (a_tap[i] >> 1)) * Sin + 2 * rp.x + (a_tap[i] & 1)) * Pp + a_p[i];
                     v = *reinterpret_cast<const float4*>(a.in + pos);
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
                 float4 v = areg[i];
                 v.x = act_pos(v.x, a.act); v.y = act_pos(v.y, a.act);
                 v.z = act_pos(v.z, a.act); v.w = act_pos(v.w, a.act);
-                *reinterpret_cast<float4*>(&As[(u / 16) * LDA + 4 * (u % 16)]) = v;
+                *reinterpret_cast<float4*>(&As[(u / (BI / 4)) * LDA + 4 * (u % (BI / 4))]) = v;
             }
         } else {
             const int bl = (int)(mbase >> (2 * a.lgSo));
@@ -532,19 +538,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         // ---- MFMA over the KM rows ------------------------------------------------------------------
 #pragma unroll 2
         for (int ks4 = 0; ks4 < KM; ks4 += 4) {
-            float av;
+            float av[RI];
             if (GEN) {
                 int64_t m = mbase + ks4 + kk;
                 if (m >= a.Mtot) m = a.Mtot - 1;             // B' rows beyond Mtot are zero
                 const RowPos rp = row_pos(m, a.lgSo);
                 const int eb = (rp.b - cur_b) * a.F * Dp;
-                av = pA < P ? Es[eb + fi * Dp + 2 * rp.y + dhA] * Es[eb + fj * Dp + 2 * rp.x + dwA] : 0.f;
+                av[0] = pA < P ? Es[eb + fi * Dp + 2 * rp.y + dhA] * Es[eb + fj * Dp + 2 * rp.x + dwA] : 0.f;
             } else {
-                av = As[(ks4 + kk) * LDA + wave * 16 + r];
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri) av[ri] = As[(ks4 + kk) * LDA + (wave * RI + ri) * 16 + r];
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                if (nt < nvalid) acc[nt] = mfma16(av, Bs[(ks4 + kk) * LDB + nt * 16 + r], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt >= nvalid) continue;
+                const float bv = Bs[(ks4 + kk) * LDB + nt * 16 + r];
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri) acc[ri][nt] = mfma16(av[ri], bv, acc[ri][nt]);
+            }
         }
         if (ib == 0 && tid < BQ) {
 #pragma unroll 8
@@ -554,15 +565,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     // ---- write this slab (every element of the parameter range, zeros included) ---------------------
     float* sw = a.slabW + (int64_t)slab * a.slab_stride;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (nt >= nvalid) continue;
-        const int q = q0 + nt * 16 + r;
+    for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = i0 + wave * 16 + kk * 4 + j;
-            sw[(int64_t)i * Pp + q] = acc[nt][j];
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nvalid) continue;
+            const int q = q0 + nt * 16 + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + (wave * RI + ri) * 16 + kk * 4 + j;
+                if (i < 4 * Pp) sw[(int64_t)i * Pp + q] = acc[ri][nt][j];
+            }
         }
-    }
     if (ib == 0 && tid < BQ && q0 + tid < Pp) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
 }
 
@@ -1894,16 +1907,16 @@ static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
     return 0;
 }
 
-template <int NT, bool GEN>
+template <int NT, bool GEN, int RI = 1>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
-    constexpr int BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
+    constexpr int BI = 64 * RI, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
     const int S2 = 1 << (2 * a.lgSo);
     const int n_ex = GEN ? (WG_KM > S2 ? WG_KM / S2 : 1) : 0;
-    const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * 80) + 4) * 4;
-    int rc = set_lds(wgrad_kernel<NT, GEN>, lds);
+    const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * (BI + 16)) + 4) * 4;
+    int rc = set_lds(wgrad_kernel<NT, GEN, RI>, lds);
     if (rc) return rc;
-    dim3 grid((unsigned)((4 * a.Pp / 64) * a.qblocks), CFFM_NSLAB);   // Pp > 64: conv_slabs() == CFFM_NSLAB
-    hipLaunchKernelGGL((wgrad_kernel<NT, GEN>), grid, dim3(256), lds, st, a);
+    dim3 grid((unsigned)(((4 * a.Pp + BI - 1) / BI) * a.qblocks), CFFM_NSLAB);   // Pp > 64: conv_slabs() == CFFM_NSLAB
+    hipLaunchKernelGGL((wgrad_kernel<NT, GEN, RI>), grid, dim3(256), lds, st, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -2185,14 +2198,21 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
     constexpr int NTH = 64 * NW, UPW = 16 / NW, KPW = 64 / NW;   // units / phase-C columns per wavefront, phase-B k-steps per wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, YT = S / 16, PpT = a.Pp, QT = PpT / 16, G = (2 * F + 15) / 16;
+    // LDS plan (74.6 KB at F32 D64: TWO workgroups per CU).  Phase B reads Tg and dCt with the LANE walking the plane /
+    // row index (m = r, y = yt*16 + r): with the natural pitch of 256 floats all sixteen lanes of a k group hit one bank
+    // (rocprofv3: SQ_LDS_BANK_CONFLICT = 82 % of SQ_LDS_IDX_ACTIVE, profiles/r02_syn1m_pmc.md).  Pitch 258 makes the Tg
+    // read conflict-free (bank = 2r + kk); dCt is staged in 16-byte pieces, so its pitch stays a multiple of 4: 260
+    // (bank = 4r + kk, 2-way).  The buffers of the epilogue (cross-wave partial sums, dEi / dEj) reuse Tg / dTg.
+    constexpr int TGP = 258, DCP = 260;
     float* Es = reinterpret_cast<float*>(smem);                // [F][Dp]
-    float* dCt = Es + (F * Dp + 3) / 4 * 4;                    // [S][16 x][16 q]
-    float* Tg = dCt + SMAX * 256;                               // [16 m][16 x][16 q]
-    float* dTg = Tg + 4096;                                     // [16 m][16 x][16 q]
-    float* part = dTg + 4096;                                   // [NW waves][4 tiles][64 lanes][4]   cross-wave sums
-    float* dEi = part + NW * 4 * 256;                            // [G*16][SMAX]    (n = dh*F + i, y)
-    float* dEj = dEi + 64 * SMAX;                               // [64][SMAX]      (n = dw*F + j, x)
-    float* rs = dEj + 64 * SMAX;                                // [F] row sums, [F] dots
+    float* dCt = Es + (F * Dp + 3) / 4 * 4;                    // [S][DCP]: (x, q) at x*16 + q
+    float* Tg = dCt + SMAX * DCP;                               // [16 m][TGP]
+    float* dTg = Tg + 16 * TGP;                                 // [16 m][16 x][16 q]  (16 * 258 floats keep it 16-byte aligned)
+    static_assert(NW * 4 * 256 <= 16 * TGP, "the cross-wave partial sums reuse Tg");
+    float* part = Tg;                                           // [NW waves][4 tiles][64 lanes][4]   cross-wave sums (epilogue)
+    float* dEi = dTg;                                           // [G*16][SMAX]    (n = dh*F + i, y)            (epilogue)
+    float* dEj = dEi + 64 * SMAX;                               // [64][SMAX]      (n = dw*F + j, x)            (epilogue)
+    float* rs = dTg + 4096;                                     // [F] row sums, [F] dots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x;
     {
@@ -2223,7 +2243,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
             __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
             for (int e4 = tid; e4 < S * 16 * 4; e4 += NTH) {   // the dC tile is staged ONCE for the four row groups
                 const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
-                *reinterpret_cast<float4*>(dCt + (y * 16 + x) * 16 + 4 * q4) =
+                *reinterpret_cast<float4*>(dCt + y * DCP + x * 16 + 4 * q4) =
                     *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
             }
 #pragma unroll
@@ -2255,7 +2275,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
                             if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Tg[(ml * 16 + kk * 4 + j) * 16 + r] = acc[j];
+                    for (int j = 0; j < 4; ++j) Tg[ml * TGP + (kk * 4 + j) * 16 + r] = acc[j];
                 }
                 if (g == 0) __syncthreads();                   // dCt staged
                 // ---- C: dT planes of the group, wave's columns 4*wave .. 4*wave+3 --------------------------------------
@@ -2267,7 +2287,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
                         const int y = 4 * s4 + kk;
                         const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
 #pragma unroll
-                        for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + UPW * wave + xl) * 16 + r], acc[xl]);
+                        for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[y * DCP + (UPW * wave + xl) * 16 + r], acc[xl]);
                     }
 #pragma unroll
                     for (int xl = 0; xl < UPW; ++xl)
@@ -2278,10 +2298,10 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
                 // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, 16 per wave), cols m -----------------
                 for (int ks = 0; ks < KPW; ++ks) {
                     const int kf = 4 * (wave * KPW + ks) + kk, x = kf >> 4, q = kf & 15;
-                    const float bv = Tg[(r * 16 + x) * 16 + q];
+                    const float bv = Tg[r * TGP + x * 16 + q];
 #pragma unroll
                     for (int yt = 0; yt < 2; ++yt)
-                        if (yt < YT) accB[g][yt] = mfma16(dCt[((yt * 16 + r) * 16 + x) * 16 + q], bv, accB[g][yt]);
+                        if (yt < YT) accB[g][yt] = mfma16(dCt[(yt * 16 + r) * DCP + x * 16 + q], bv, accB[g][yt]);
                 }
                 // ---- E: dEj rows (dw,j), K = q, cols x: this wave's four units ------------------------------------------
 #pragma unroll
@@ -2366,7 +2386,8 @@ static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
     const int S = a.D / 2;
     if (S > 32 || 2 * a.F > 64) return CFFM_ERR_UNSUPPORTED;
     constexpr int NW = 4;                // measured at F32 D64 B8192: 118 ms with 4 wavefronts, 194 ms with 8 (register spills)
-    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 4096 + 4096 + NW * 4 * 256 + 64 * 32 + 64 * 32 + 2 * a.F) * 4 + 16;
+    // Es | dCt [32][260] | Tg [16][258] | dTg [4096] | rs [2F]
+    const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 260 + 16 * 258 + 4096 + 2 * a.F) * 4 + 16;
     int rc = set_lds(conv0_fact_tile_dgrad_kernel<32, NW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((conv0_fact_tile_dgrad_kernel<32, NW>), dim3(a.B), dim3(64 * NW), lds, st, a);
@@ -2713,6 +2734,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
         if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) { rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st); }
         else if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
+        else if (NT == 8) { rc = launch_wgrad<8, false, 2>(a, st); }      // full 128-column tiles: 128 x 128 output tile per workgroup
         else { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, false>(a, st))); }
         if (rc) return rc;
         }
