@@ -29,6 +29,18 @@
 #define KSTEP 32
 #define WG_KM 64       // rows of the M (reduction) dimension staged per wgrad step
 
+// XCD-aware blockIdx -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), and
+// every XCD has an L2 of its own: tiles that read the SAME operand rows should therefore be consecutive blocks OF ONE XCD,
+// not consecutive block ids.  A launch of 8 * per_xcd blocks: XCD x = id & 7 works through the contiguous range
+// [x * per_xcd, (x + 1) * per_xcd) of the logical tile order (the operand-sharing index fastest) in the order w = id >> 3.
+// Placement is only a speed assumption (MI355X_MICROARCH.md: dispatch order is not a contract): any block -> XCD map
+// gives the same results.
+__device__ __forceinline__ int64_t xcd_tile(int64_t per_xcd) {
+    const int64_t id = blockIdx.x;
+    return (id & 7) * per_xcd + (id >> 3);
+}
+__host__ __device__ static inline int64_t xcd_per(int64_t tiles) { return (tiles + 7) / 8; }
+
 struct RowPos { int b, y, x; };
 __device__ __forceinline__ RowPos row_pos(int64_t m, int lgSo) {
     RowPos p;
@@ -41,61 +53,109 @@ __device__ __forceinline__ RowPos row_pos(int64_t m, int lgSo) {
 
 // -------------------------------------------------------------------------------------------------
 // Generic K loop: acc[RM][NT] += A(rows of this wave, K) * Wtile(K, BN).
-//   loadA(ks, areg): fills areg[RM][2] (float4 = 4 consecutive k of the lane's row, halves h = 0,1)
-//   loadW(ks, wreg): fills wreg[2*NT]; element e = tid + 256*i is tile[e / BN][e % BN], or with TRANS
-//                    tile[e % 32][e / 32] (lets the loader read a transposed weight contiguously)
-//   khalves: number of valid 16-deep halves (K / 16)
+//   loadA(ks, areg): fills areg[RM][2] (float4 = 4 consecutive k of the lane's row, halves h = 0,1 of the 32-deep step)
+//   w: where the weight tile comes from.  TRANS = false: element (k, n) = w.W[k * w.ld + n] (forward: HWIO filter);
+//      TRANS = true: element (k, n) = w.W[n * w.ld + k] (input gradient: the same filter read transposed).  Elements with
+//      k >= w.k_lim or n >= w.n_lim are zeros (k_lim is a multiple of 16: a group of 4 consecutive k is in or out as one).
+//   khalves: number of valid 16-deep halves of the K dimension
+// The weight tile of a step lives in LDS as [8 k-quads][BN columns][4 k]: a thread stages whole (k-quad, column) records
+// with ONE 16-byte store at 16 * its index (conflict-free), and a lane's B fragments of the four MFMAs that consume one
+// float4 of A come back with ONE ds_read_b128 per column tile (lanes of a k group read 256 contiguous bytes).  Every
+// tile of the wave is computed (columns beyond n_lim are zeros; the callers' epilogues skip them): no branch sits between
+// the MFMAs of a step, so the compiler keeps the global loads of the next step in flight behind them.
 // -------------------------------------------------------------------------------------------------
-template <int NT, int RM, bool TRANS, class LoadA, class LoadW>
-__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, float* Ws, int nvalid,
-                                          LoadA loadA, LoadW loadW) {
-    constexpr int BN = NT * 16, LDW = BN + 4;
+// act on four values known to be >= 0 (see act_pos): ONE wave-uniform branch for the whole group instead of a switch per
+// element - relu / prelu / elu are the identity there
+__device__ __forceinline__ void act_pos4(float4& c, int act) {
+    if (act == CFFM_ACT_SELU) {
+        c.x *= CFFM_SELU_SCALE; c.y *= CFFM_SELU_SCALE; c.z *= CFFM_SELU_SCALE; c.w *= CFFM_SELU_SCALE;
+    } else if (act == CFFM_ACT_GELU) {
+        c.x = act_pos(c.x, CFFM_ACT_GELU); c.y = act_pos(c.y, CFFM_ACT_GELU);
+        c.z = act_pos(c.z, CFFM_ACT_GELU); c.w = act_pos(c.w, CFFM_ACT_GELU);
+    }
+}
+
+struct WSpec { const float* W; int ld, k_lim, n_lim, n0; };
+
+template <int NT, int RM, bool TRANS, class LoadA>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, float* Ws, const WSpec w, LoadA loadA, int actA = CFFM_ACT_RELU) {
+    constexpr int BN = NT * 16;
+    constexpr int NREC = 8 * BN;                       // (k-quad, column) records of one step
+    constexpr int NP = (NREC + 255) / 256;             // records per thread
+    constexpr int WBUF = NREC * 4;                     // floats per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
     const int nks = (khalves + 1) >> 1;
     float4 areg[RM][2], anext[RM][2];
-    float wreg[2 * NT];
-    loadA(0, areg);
-    loadW(0, wreg);
-    __syncthreads();                          // previous users of Ws are done
+    float4 w4[NP];
+    auto fetchW = [&](int ks) {
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) {
-        const int e = tid + 256 * i;
-        Ws[TRANS ? (e % KSTEP) * LDW + (e / KSTEP) : (e / BN) * LDW + (e % BN)] = wreg[i];
-    }
+        for (int i = 0; i < NP; ++i) {
+            const int rec = tid + 256 * i, kq = rec / BN, c = rec - kq * BN;
+            const int k = ks * KSTEP + 4 * kq, n = w.n0 + c;
+            const bool ok = (NREC % 256 == 0 || rec < NREC) && k < w.k_lim && n < w.n_lim;
+            // unconditional loads from a clamped address, zeroed by a select: no exec-mask branch around a load
+            const int kc = k < w.k_lim ? k : w.k_lim - 4, nc = n < w.n_lim ? n : w.n_lim - 1;
+            float4 v;
+            if (TRANS) {
+                v = *reinterpret_cast<const float4*>(w.W + (int64_t)nc * w.ld + kc);
+            } else {
+                const float* src = w.W + (int64_t)kc * w.ld + nc;
+                v = make_float4(src[0], src[w.ld], src[2 * w.ld], src[3 * w.ld]);
+            }
+            w4[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto storeW = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int rec = tid + 256 * i;
+            if (NREC % 256 == 0 || rec < NREC) *reinterpret_cast<float4*>(buf + 4 * rec) = w4[i];
+        }
+    };
+    loadA(0, areg);
+    fetchW(0);
+    __syncthreads();                          // previous users of Ws are done
+    storeW(Ws);
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
         const bool more = ks + 1 < nks;
         if (more) {
             loadA(ks + 1, anext);
-            loadW(ks + 1, wreg);
+            fetchW(ks + 1);
         }
-        const float* Wb = Ws + (ks & 1) * (KSTEP * LDW);
+        // the activation of the A operand (forward: act(C_{l-1}), C >= 0) is applied HERE, to the operands loaded one
+        // step ago - not at load time, where it would put a wait for the prefetch right behind its issue
+        if (actA != CFFM_ACT_RELU && actA != CFFM_ACT_PRELU && actA != CFFM_ACT_ELU) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) act_pos4(areg[rm][h], actA);
+        }
+        const float* Wb = Ws + (ks & 1) * WBUF;
+        const int nh = (ks == nks - 1 && (khalves & 1)) ? 1 : 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (2 * ks + h < khalves) {
+            if (h < nh) {
+                float4 bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bf[nt] = *reinterpret_cast<const float4*>(Wb + ((h * 4 + kk) * BN + nt * 16 + r) * 4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int krow = 16 * h + 4 * kk + t;
-                    float bf[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bf[nt] = Wb[krow * LDW + nt * 16 + r];
 #pragma unroll
                     for (int rm = 0; rm < RM; ++rm) {
                         const float av = t == 0 ? areg[rm][h].x : t == 1 ? areg[rm][h].y : t == 2 ? areg[rm][h].z : areg[rm][h].w;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            if (nt < nvalid) acc[rm][nt] = mfma16(av, bf[nt], acc[rm][nt]);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const float bv = t == 0 ? bf[nt].x : t == 1 ? bf[nt].y : t == 2 ? bf[nt].z : bf[nt].w;
+                            acc[rm][nt] = mfma16(av, bv, acc[rm][nt]);
+                        }
                     }
                 }
             }
         }
         if (more) {
-            float* Wn = Ws + ((ks + 1) & 1) * (KSTEP * LDW);
-#pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) {
-                const int e = tid + 256 * i;
-                Wn[TRANS ? (e % KSTEP) * LDW + (e / KSTEP) : (e / BN) * LDW + (e % BN)] = wreg[i];
-            }
+            storeW(Ws + ((ks + 1) & 1) * WBUF);
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) { areg[rm][0] = anext[rm][0]; areg[rm][1] = anext[rm][1]; }
         }
@@ -122,6 +182,7 @@ struct ConvArgs {
     float* out;          // relu(conv + bias) [B,So,So,Pp]
     int64_t Mtot;        // B*So*So
     int B, lgSo, P, Pp, F, D, act;
+    int nblk;            // conv_fwd_kernel: column blocks of a row tile (the grid is 1-D, see xcd_tile)
 };
 
 template <int NT, int RM, bool GEN>
@@ -134,8 +195,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1;
     const float invPp = 1.f / (float)Pp;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // the nblk column blocks of one row tile read the same A rows: consecutive blocks of one XCD
+    const int64_t mtiles = (a.Mtot + BM - 1) / BM;
+    const int64_t tile = xcd_tile(xcd_per(mtiles) * a.nblk);
+    if (tile >= mtiles * a.nblk) return;
+    const int64_t m0 = (tile / a.nblk) * BM;
+    const int n0 = (int)(tile % a.nblk) * BN;
     const int nvalid = min(NT, (Pp - n0) / 16);
 
     int64_t abase[RM];   // !GEN: float offset of the (dh=0,dw=0) patch row piece of this lane
@@ -183,30 +248,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             } else {
                 const int64_t toff = (int64_t)(dh * Sin + dw) * Pp + pb;
 #pragma unroll
-                for (int rm = 0; rm < RM; ++rm) {
-                    float4 c = *reinterpret_cast<const float4*>(a.in + abase[rm] + toff);
-                    c.x = act_pos(c.x, a.act); c.y = act_pos(c.y, a.act);
-                    c.z = act_pos(c.z, a.act); c.w = act_pos(c.w, a.act);
-                    reg[rm][h] = c;
-                }
+                for (int rm = 0; rm < RM; ++rm)
+                    reg[rm][h] = *reinterpret_cast<const float4*>(a.in + abase[rm] + toff);
             }
         }
     };
-    auto loadW = [&](int ks, float (&wreg)[2 * NT]) {
-#pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int e = tid + 256 * i, kr = e / BN, c = e % BN;
-            const int k = ks * KSTEP + kr, n = n0 + c;
-            wreg[i] = (k < 4 * Pp && n < Pp) ? a.W[k * Pp + n] : 0.f;
-        }
-    };
+    const WSpec wspec = {a.W, Pp, 4 * Pp, Pp, n0};
 
     f32x4 acc[RM][NT];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, nvalid, loadA, loadW);
+    gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, GEN ? CFFM_ACT_RELU : a.act);   // act(C_{l-1}) on the A operand
 
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
@@ -235,6 +289,7 @@ struct DgradArgs {
     float* dprev;        // L0=false: dC_{l-1};  L0=true: dEo [B,F,D]
     int64_t Mtot;
     int B, lgSo, P, Pp, F, D, act, t1w, t1off;   // t1off: offset of this layer's input pool inside t1
+    int nblk;            // dgrad_kernel, L0 = false: column blocks of a row tile (1-D grid, see xcd_tile)
 };
 
 template <int NT, int RM, bool L0>
@@ -252,7 +307,13 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
     const int mtiles = rows_per_wg / BM;
     const int nblocks = L0 ? (Ntot + BN - 1) / BN : 1;
-    const int64_t wg_m0 = (int64_t)blockIdx.x * rows_per_wg;
+    // L0 = false: the nblk column blocks of one row tile read the same dC rows: consecutive blocks of one XCD
+    const int nby = L0 ? 1 : a.nblk;
+    const int64_t mtiles_wg = (a.Mtot + rows_per_wg - 1) / rows_per_wg;
+    const int64_t tile = xcd_tile(xcd_per(mtiles_wg) * nby);
+    if (tile >= mtiles_wg * nby) return;
+    const int64_t wg_m0 = (tile / nby) * rows_per_wg;
+    const int by = (int)(tile % nby);
     const int b0 = (int)(wg_m0 >> (2 * a.lgSo));
     const int exsz = a.F * Dp;
     float* dEw = Es + n_ex * exsz + wave * (n_ex * exsz);     // this wave's private accumulators
@@ -266,7 +327,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
     }
 
     for (int nb = 0; nb < nblocks; ++nb) {
-        const int n0 = (L0 ? nb : blockIdx.y) * BN;
+        const int n0 = (L0 ? nb : by) * BN;
         const int nvalid = min(NT, (Ntot - n0) / 16);
         // fast path, j-side: dEo[j_p][2x+dw] sums over y and dh -> keep it in registers across the m tiles
         float accj[RM][NT][4];
@@ -291,29 +352,60 @@ __global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
                 for (int h = 0; h < 2; ++h) {
                     const int k = ks * KSTEP + 16 * h;
 #pragma unroll
-                    for (int rm = 0; rm < RM; ++rm)
-                        reg[rm][h] = k < Pp ? *reinterpret_cast<const float4*>(a.dC + arow[rm] + k)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int rm = 0; rm < RM; ++rm)       // k >= Pp only in the unused second half of an odd last step
+                        reg[rm][h] = *reinterpret_cast<const float4*>(a.dC + arow[rm] + (k < Pp ? k : Pp - 16));
                 }
             };
-            auto loadW = [&](int ks, float (&wreg)[2 * NT]) {   // W^T tile: [q][n], global read contiguous in q
-#pragma unroll
-                for (int i = 0; i < 2 * NT; ++i) {
-                    const int e = tid + 256 * i, c = e / KSTEP, kr = e % KSTEP;
-                    const int q = ks * KSTEP + kr, n = n0 + c;
-                    wreg[i] = (q < Pp && n < Ntot) ? a.W[n * Pp + q] : 0.f;
-                }
-            };
+            const WSpec wspec = {a.W, Pp, Pp, Ntot, n0};        // W^T tile: (k = q, n) = W[n][q], 16-byte reads along q
             f32x4 acc[RM][NT];
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, nvalid, loadA, loadW);
+            gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
 
             // ---- epilogue ------------------------------------------------------------------------
+            if (!L0) {
+                // scatter-store fused with the broadcast sum-pool gradient and the relu/act mask (patches never overlap).
+                // Everything that depends only on the column (tap, p) or only on the row (b, y, x) is computed once:
+                // the per-element work is one add, one load of C_{l-1}, one mask and one store.
+                int noff[NT], ndh[NT];
+                // d act(relu(z)) / dz through c = relu(z) > 0: 1 for relu / prelu / elu, the scale for selu; gelu needs c
+                const float gsc = a.act == CFFM_ACT_SELU ? CFFM_SELU_SCALE : 1.f;
+                const bool gel = a.act == CFFM_ACT_GELU;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + nt * 16 + r, tap = fast_div(n, invPp), p = n - tap * Pp;
+                    ndh[nt] = tap >> 1;
+                    noff[nt] = ((tap >> 1) * Sin + (tap & 1)) * Pp + p;
+                }
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t m = mrow + j;
+                        if (m >= a.Mtot) continue;
+                        const RowPos rp = row_pos(m, a.lgSo);
+                        const int64_t rowbase = (((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp;
+                        const float* tp = a.dt1 + (int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y;
+                        const float t0 = tp[0], t1v = tp[1];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if (nt >= nvalid) continue;
+                            const int64_t pos = rowbase + noff[nt];
+                            const float g = acc[rm][nt][j] + (ndh[nt] ? t1v : t0);
+                            const float c = a.Cprev[pos];
+                            float d = c > 0.f ? gsc : 0.f;
+                            if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
+                            a.dprev[pos] = g * d;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) {
+                if (!L0) break;
                 const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
                 const RowPos rq = row_pos(mrow < a.Mtot ? mrow : a.Mtot - 1, a.lgSo);   // fast path: (b, y) of the tile
 #pragma unroll
@@ -430,6 +522,7 @@ struct WgradArgs {
     float* slabB;        // slab 0 of conv_b[l]
     int64_t slab_stride, slabB_stride, Mtot;
     int B, lgSo, P, Pp, F, D, act, qblocks;
+    int nslab, nxy;      // wgrad_kernel: gradient slabs and output tiles per slab (1-D grid, see xcd_tile)
 };
 
 // RI row tiles per wavefront: the workgroup's output tile is (64*RI) x (16*NT).  RI = 2 halves the dC traffic per MFMA
@@ -448,12 +541,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
     const float invPp = 1.f / (float)Pp;
-    const int ib = blockIdx.x / a.qblocks, qb = blockIdx.x - ib * a.qblocks;
+    // all output tiles of ONE slab read the same rows of A' and dC: they run as consecutive blocks of one XCD, which
+    // then works through its slabs one after the other (the operands reach the XCD's L2 once per slab)
+    const int64_t tile = xcd_tile(xcd_per(a.nslab) * a.nxy);
+    if (tile >= (int64_t)a.nslab * a.nxy) return;
+    const int slab = (int)(tile / a.nxy), bxy = (int)(tile % a.nxy);
+    const int ib = bxy / a.qblocks, qb = bxy - ib * a.qblocks;
     const int i0 = ib * BI, q0 = qb * BQ;
     const int nvalid = min(NT, (Pp - q0) / 16);
-    const int slab = blockIdx.y;
     const int64_t nsteps = (a.Mtot + KM - 1) / KM;
-    const int64_t cps = (nsteps + gridDim.y - 1) / gridDim.y;
+    const int64_t cps = (nsteps + a.nslab - 1) / a.nslab;
     const int64_t s_lo = slab * cps, s_hi = min(nsteps, s_lo + cps);
     const int n_ex = GEN ? (KM > S2 ? KM / S2 : 1) : 0;
 
@@ -560,6 +657,155 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         if (ib == 0 && tid < BQ) {
 #pragma unroll 8
             for (int row = 0; row < KM; ++row) bsum += Bs[row * LDB + tid];
+        }
+    }
+    // ---- write this slab (every element of the parameter range, zeros included) ---------------------
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride;
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nvalid) continue;
+            const int q = q0 + nt * 16 + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + (wave * RI + ri) * 16 + kk * 4 + j;
+                if (i < 4 * Pp) sw[(int64_t)i * Pp + q] = acc[ri][nt][j];
+            }
+        }
+    if (ib == 0 && tid < BQ && q0 + tid < Pp) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
+}
+
+// wgrad2: the weight / bias gradient of a conv layer >= 1 for WIDE filters (Pp > 64), same contraction and same split-K
+// slabs as wgrad_kernel<.., GEN = false>, restructured after the rocprofv3 counters of round 2 (MFMA pipe 40 % busy, one
+// exposed LDS round trip per two MFMAs: every B fragment was a ds_read_b32 followed by its own wait and a branch):
+//   * both operands are fetched in 16-byte pieces as 4 x 4 blocks (4 consecutive reduction rows m x 4 consecutive
+//     channels), transposed in registers and staged as [m/4][channel][4 m] records - the layout gemm_tile uses - so that a
+//     lane's fragments for FOUR MFMAs come back with one ds_read_b128 (a float4 = 4 consecutive m; A' and dC use the same
+//     k permutation);
+//   * every tile of the wave is computed (columns beyond Pp and rows beyond 4*Pp are staged as zeros; the slab write skips
+//     them): no branch and no wait sits between the MFMAs of a 16-row chunk;
+//   * out-of-range rows / columns are read from a clamped address and zeroed by a select (no exec-mask branches).
+// Output tile 128 x (16*NT) per workgroup, wave w owns rows [32 w, 32 w + 32): acc[2][NT].
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgradArgs a) {
+    constexpr int RI = 2, BI = 64 * RI, BQ = NT * 16, KM = WG_KM, MQ = KM / 4;
+    constexpr int NBA = MQ * (BI / 4) / 256, NBB = (MQ * (BQ / 4) + 255) / 256;   // 4x4 blocks per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                       // [MQ][BI][4]
+    float* Bs = As + MQ * BI * 4;                                     // [MQ][BQ][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp;
+    const float invPp = 1.f / (float)Pp;
+    const int64_t tile = xcd_tile(xcd_per(a.nslab) * a.nxy);
+    if (tile >= (int64_t)a.nslab * a.nxy) return;
+    const int slab = (int)(tile / a.nxy), bxy = (int)(tile % a.nxy);
+    const int ib = bxy / a.qblocks, qb = bxy - ib * a.qblocks;
+    const int i0 = ib * BI, q0 = qb * BQ;
+    const int nvalid = min(NT, (Pp - q0) / 16);
+    const int64_t nsteps = (a.Mtot + KM - 1) / KM;
+    const int64_t cps = (nsteps + a.nslab - 1) / a.nslab;
+    const int64_t s_lo = slab * cps, s_hi = min(nsteps, s_lo + cps);
+
+    // staging geometry of this thread (fixed over the steps)
+    int a_off[NBA], a_mq[NBA], a_i4[NBA];                         // A': float offset of (tap, p) inside a patch, or -1 (zeros)
+#pragma unroll
+    for (int j = 0; j < NBA; ++j) {
+        const int bb = tid + 256 * j;
+        a_mq[j] = bb / (BI / 4); a_i4[j] = bb % (BI / 4);
+        const int ii = i0 + 4 * a_i4[j], tap = fast_div(ii, invPp), p = ii - tap * Pp;
+        a_off[j] = tap < 4 ? ((tap >> 1) * Sin + (tap & 1)) * Pp + p : -1;
+    }
+    f32x4 acc[RI][NT];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ri][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    float4 areg[NBA][4], breg[NBB][4];
+
+    auto fetch = [&](int64_t st) {            // global -> registers for step st
+        const int64_t mbase = st * KM;
+#pragma unroll
+        for (int j = 0; j < NBA; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t m = mbase + 4 * a_mq[j] + t;
+                const bool ok = m < a.Mtot && a_off[j] >= 0;
+                const RowPos rp = row_pos(m < a.Mtot ? m : a.Mtot - 1, a.lgSo);
+                const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp + (a_off[j] >= 0 ? a_off[j] : 0);
+                const float4 v = *reinterpret_cast<const float4*>(a.in + pos);
+                areg[j][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) {
+            const int bb = tid + 256 * j, mq = bb / (BQ / 4), c4 = bb % (BQ / 4);
+            const int q = q0 + 4 * c4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t m = mbase + 4 * mq + t;
+                const bool ok = (MQ * (BQ / 4) % 256 == 0 || bb < MQ * (BQ / 4)) && m < a.Mtot && q < Pp;
+                const int64_t mc = m < a.Mtot ? m : a.Mtot - 1;
+                const float4 v = *reinterpret_cast<const float4*>(a.dC + mc * Pp + (q < Pp ? q : Pp - 4));
+                breg[j][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    // 4 x 4 block (rows t = 4 consecutive m, columns = 4 consecutive channels) -> 4 records (one per channel) of 4 m each
+    auto put = [&](float* dst, const float4 (&b)[4]) {
+        *reinterpret_cast<float4*>(dst) = make_float4(b[0].x, b[1].x, b[2].x, b[3].x);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(b[0].y, b[1].y, b[2].y, b[3].y);
+        *reinterpret_cast<float4*>(dst + 8) = make_float4(b[0].z, b[1].z, b[2].z, b[3].z);
+        *reinterpret_cast<float4*>(dst + 12) = make_float4(b[0].w, b[1].w, b[2].w, b[3].w);
+    };
+
+    if (s_lo < s_hi) fetch(s_lo);
+    for (int64_t st = s_lo; st < s_hi; ++st) {
+        __syncthreads();                                   // previous step's LDS reads are done
+        if (a.act != CFFM_ACT_RELU && a.act != CFFM_ACT_PRELU && a.act != CFFM_ACT_ELU) {
+#pragma unroll
+            for (int j = 0; j < NBA; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) act_pos4(areg[j][t], a.act);     // A' = act(C_{l-1}), C >= 0
+        }
+#pragma unroll
+        for (int j = 0; j < NBA; ++j) put(As + (a_mq[j] * BI + 4 * a_i4[j]) * 4, areg[j]);
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) {
+            const int bb = tid + 256 * j, mq = bb / (BQ / 4), c4 = bb % (BQ / 4);
+            if (MQ * (BQ / 4) % 256 == 0 || bb < MQ * (BQ / 4)) put(Bs + (mq * BQ + 4 * c4) * 4, breg[j]);
+        }
+        __syncthreads();
+        if (st + 1 < s_hi) fetch(st + 1);                 // in flight while this step's MFMAs run
+        // ---- MFMA: 4 chunks of 16 reduction rows; lane (r, kk) takes record m/4 = 4 * chunk + kk ---------------------
+#pragma unroll
+        for (int ch = 0; ch < MQ / 4; ++ch) {
+            float4 af[RI], bf[NT];
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+                af[ri] = *reinterpret_cast<const float4*>(As + ((4 * ch + kk) * BI + (wave * RI + ri) * 16 + r) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[nt] = *reinterpret_cast<const float4*>(Bs + ((4 * ch + kk) * BQ + nt * 16 + r) * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = t == 0 ? bf[nt].x : t == 1 ? bf[nt].y : t == 2 ? bf[nt].z : bf[nt].w;
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) {
+                        const float av = t == 0 ? af[ri].x : t == 1 ? af[ri].y : t == 2 ? af[ri].z : af[ri].w;
+                        acc[ri][nt] = mfma16(av, bv, acc[ri][nt]);
+                    }
+                }
+        }
+        if (ib == 0 && tid < BQ) {                         // db[q] += sum over the KM rows, in row order
+#pragma unroll 4
+            for (int mq = 0; mq < MQ; ++mq) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + (mq * BQ + tid) * 4);
+                bsum += v.x; bsum += v.y; bsum += v.z; bsum += v.w;
+            }
         }
     }
     // ---- write this slab (every element of the parameter range, zeros included) ---------------------
@@ -1886,8 +2132,11 @@ static int launch_conv_fwd(const ConvArgs& a, int nblk, hipStream_t st) {
     const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 0) + 4) * 4;
     int rc = set_lds(conv_fwd_kernel<NT, RM, GEN>, lds);
     if (rc) return rc;
-    dim3 grid((unsigned)((a.Mtot + BM - 1) / BM), nblk);
-    hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN>), grid, dim3(256), lds, st, a);
+    ConvArgs b = a;
+    b.nblk = nblk;
+    const int64_t nb1 = 8 * xcd_per((a.Mtot + BM - 1) / BM) * nblk;
+    if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN>), dim3((unsigned)nb1), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1901,8 +2150,11 @@ static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
     const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (L0 ? a.Pp + 5 * n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F : 0) + 4) * 4;
     int rc = set_lds(dgrad_kernel<NT, RM, L0>, lds);
     if (rc) return rc;
-    dim3 grid((unsigned)((a.Mtot + rows_per_wg - 1) / rows_per_wg), L0 ? 1 : nblk);
-    hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0>), grid, dim3(256), lds, st, a);
+    DgradArgs b = a;
+    b.nblk = L0 ? 1 : nblk;
+    const int64_t nb1 = 8 * xcd_per((a.Mtot + rows_per_wg - 1) / rows_per_wg) * b.nblk;
+    if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0>), dim3((unsigned)nb1), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1915,8 +2167,25 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * (BI + 16)) + 4) * 4;
     int rc = set_lds(wgrad_kernel<NT, GEN, RI>, lds);
     if (rc) return rc;
-    dim3 grid((unsigned)(((4 * a.Pp + BI - 1) / BI) * a.qblocks), CFFM_NSLAB);   // Pp > 64: conv_slabs() == CFFM_NSLAB
-    hipLaunchKernelGGL((wgrad_kernel<NT, GEN, RI>), grid, dim3(256), lds, st, a);
+    WgradArgs b = a;
+    b.nslab = CFFM_NSLAB;                                                       // Pp > 64: conv_slabs() == CFFM_NSLAB
+    b.nxy = ((4 * a.Pp + BI - 1) / BI) * a.qblocks;
+    dim3 grid((unsigned)(8 * xcd_per(b.nslab) * b.nxy));
+    hipLaunchKernelGGL((wgrad_kernel<NT, GEN, RI>), grid, dim3(256), lds, st, b);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT>
+static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
+    constexpr int BI = 128, BQ = NT * 16;
+    const size_t lds = (size_t)(WG_KM * BI + WG_KM * BQ) * 4 + 16;
+    int rc = set_lds(wgrad2_kernel<NT>, lds);
+    if (rc) return rc;
+    WgradArgs b = a;
+    b.nslab = CFFM_NSLAB;                                                       // Pp > 64: conv_slabs() == CFFM_NSLAB
+    b.nxy = ((4 * a.Pp + BI - 1) / BI) * a.qblocks;
+    hipLaunchKernelGGL((wgrad2_kernel<NT>), dim3((unsigned)(8 * xcd_per(b.nslab) * b.nxy)), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -2734,7 +3003,8 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
         if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) { rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st); }
         else if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
-        else if (NT == 8) { rc = launch_wgrad<8, false, 2>(a, st); }      // full 128-column tiles: 128 x 128 output tile per workgroup
+        else if (NT == 8) { rc = launch_wgrad2<8>(a, st); }               // 128 x 128 output tile per workgroup
+        else if (NT == 6) { rc = launch_wgrad2<6>(a, st); }               // 128 x 96
         else { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, false>(a, st))); }
         if (rc) return rc;
         }
