@@ -129,8 +129,14 @@ class CFFM(object):
     # ---- engine / data residency -----------------------------------------------------------------------
     def build_graph(self):
         """Creates the device state (the reference builds the TF graph here, CFFM.py:531-541)."""
+        import torch
         from .engine import HipEngine
-        self.engine = HipEngine(self.config, seed=self.random_seed)
+        # one process per GPU: the device is the launcher's LOCAL_RANK (torch.distributed.run) or the process's current
+        # device; it is made current so that the library's launches and torch's stream agree on it
+        dev = int(os.environ.get('LOCAL_RANK', torch.cuda.current_device() if torch.cuda.is_available() else 0))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(dev)
+        self.engine = HipEngine(self.config, seed=self.random_seed, device='cuda:%d' % dev)
         if self.pretrain_flag > 0:
             self.load(self.save_file)
         return self.engine
@@ -296,18 +302,26 @@ class CFFM(object):
         if not os.path.exists(save_file):
             os.makedirs(save_file)
 
-    # ---- checkpoint: this model's tensors AND the Adagrad accumulators (the reference restore is broken, Q7) ---
+    # ---- checkpoint: this model's tensors AND the optimizer slots (the reference restore is broken, Q7) ---------------
+    # A plain dict of tensors and scalars: loads with torch.load(weights_only=True), no pickled code.
     def save(self, save_file):
         import torch
-        torch.save({'config': self.config.__dict__, 'params': self.engine.export_params(),
-                    'accumulators': self.engine.export_accumulators(),
-                    'second_moments': self.engine.export_second_moments(), 'opt_step': self.engine.opt_step},
+        t = lambda d: None if d is None else {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+        cfg = {k: (v if isinstance(v, (int, float, str)) else float(v)) for k, v in self.config.__dict__.items()}
+        torch.save({'format': 2, 'config': cfg, 'params': t(self.engine.export_params()),
+                    'accumulators': t(self.engine.export_accumulators()),
+                    'second_moments': t(self.engine.export_second_moments()), 'opt_step': int(self.engine.opt_step)},
                    save_file + '.pt')
 
     def load(self, save_file):
         import torch
-        blob = torch.load(save_file + '.pt', weights_only=False)
-        self.engine.load_params(blob['params'], blob['accumulators'], blob.get('second_moments'))
+        blob = torch.load(save_file + '.pt', weights_only=True)
+        n = lambda d: None if d is None else {k: (v.numpy() if hasattr(v, 'numpy') else np.asarray(v)) for k, v in d.items()}
+        saved = blob.get('config', {})
+        for k in ('M', 'F', 'K', 'D'):
+            if k in saved and int(saved[k]) != int(getattr(self.config, k)):
+                raise ValueError('checkpoint %s.pt was written for %s=%s, this model has %s' % (save_file, k, saved[k], getattr(self.config, k)))
+        self.engine.load_params(n(blob['params']), n(blob['accumulators']), n(blob.get('second_moments')))
         self.engine.opt_step = int(blob.get('opt_step', 0))
 
 

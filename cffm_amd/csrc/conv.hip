@@ -2265,6 +2265,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
             bw[ks] = ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f;
             av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
         }
+        // (measured at F32 D64: unconditional chains of 16/8 or 16/12/8/4 MFMAs ran this kernel 8 % and 20 % SLOWER than
+        // the test per k-step below - the forward has one unit per wave and step, so the skipped MFMAs are what counts)
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C0T_MAXKS; ++ks)
@@ -2536,12 +2538,21 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
                             const int k = 4 * ks + kk;
                             const bool ok = k < K;
                             const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
-                            bw[ks] = ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f;
-                            av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * (x0 + r) + dw] : 0.f;
+                            // (i = F-1 has no pairs: K = 0, base = P - keep the discarded reads inside W and Es)
+                            const float wv = a.W[((int64_t)(dh * 2 + dw) * PpT + min(base + jj, a.P - 1)) * PpT + q0 + r];
+                            const float ev = Es[min(i + 1 + jj, F - 1) * Dp + 2 * (x0 + r) + dw];
+                            bw[ks] = ok ? wv : 0.f;
+                            av[ks] = ok ? ev : 0.f;
                         }
+                        // two straight chains instead of a test per MFMA (a branch and a full wait in front of each):
+                        // 64.2 ms against 68.7 with the tests and 67.9 with four chain lengths (F32 D64 B8192)
+                        if (K > 2 * C0T_MAXKS) {
 #pragma unroll
-                        for (int ks = 0; ks < C0T_MAXKS; ++ks)
-                            if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);
+                            for (int ks = 0; ks < C0T_MAXKS; ++ks) acc = mfma16(av[ks], bw[ks], acc);
+                        } else {
+#pragma unroll
+                            for (int ks = 0; ks < C0T_MAXKS / 2; ++ks) acc = mfma16(av[ks], bw[ks], acc);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Tg[ml * TGP + (kk * 4 + j) * 16 + r] = acc[j];
@@ -2587,8 +2598,9 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
                         const bool any = (t * 16 < F && jmax_lo > i) || (t * 16 + 15 >= F && jmax_hi > i && t * 16 < 2 * F);
                         if (!any) continue;
                         const bool ok = n < 2 * F && j > i;
-                        const float4 wv = ok ? *reinterpret_cast<const float4*>(a.W + ((int64_t)(dh * 2 + dw) * PpT + base + j - i - 1) * PpT + q0 + 4 * kk)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int jc = ok ? j - i - 1 : 0, dwc = ok ? dw : 0;            // clamped row, zeroed by the select
+                        float4 wv = *reinterpret_cast<const float4*>(a.W + ((int64_t)(dh * 2 + dwc) * PpT + base + jc) * PpT + q0 + 4 * kk);
+                        if (!ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
                         accE[xt][t] = mfma16(wv.x, bv.x, accE[xt][t]);
                         accE[xt][t] = mfma16(wv.y, bv.y, accE[xt][t]);
                         accE[xt][t] = mfma16(wv.z, bv.z, accE[xt][t]);
@@ -3141,7 +3153,7 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
     fa.live = g.live; fa.n_rows = B * s->F; fa.B = B;
     fa.rank_keys = rank_keys ? 1 : 0;
     int bits = 1;
-    while ((1ll << bits) < (long long)s->M && bits < 31) ++bits;
+    while ((1ll << bits) <= (long long)s->M && bits < 31) ++bits;
     fa.id_bits = bits;
     const int S = g.D / 2, PP = g.Pp;
     size_t lds = inner_fwd_lds(g);

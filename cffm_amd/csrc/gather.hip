@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             const int raw = ids[s];
             const int id = raw < 0 ? 0 : (raw >= M ? M - 1 : raw);
             if (fb != nullptr) fb[s] = fbias[id];
-            if (keys != nullptr) keys[s] = ((unsigned long long)(unsigned)raw << 32) | (unsigned long long)s;
+            if (keys != nullptr) keys[s] = ((unsigned long long)(unsigned)((raw < 0 || raw >= M) ? M : raw) << 32) | (unsigned long long)s;   // bad id -> key M
         }
     }
 }

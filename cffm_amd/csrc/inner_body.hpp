@@ -74,7 +74,7 @@ __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, ch
             const int id = raw < 0 ? 0 : (raw >= fg.M ? fg.M - 1 : raw);
             const int64_t slot = (int64_t)b * g.F + threadIdx.x;
             fg.fb[slot] = fg.fbias[id];
-            fg.keys[slot] = ((unsigned long long)(unsigned)raw << 32) | (unsigned long long)slot;
+            fg.keys[slot] = ((unsigned long long)(unsigned)((raw < 0 || raw >= fg.M) ? fg.M : raw) << 32) | (unsigned long long)slot;   // bad id -> key M
         }
     } else {
         const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * g.F * g.K);

@@ -228,10 +228,16 @@ int cffm_dp_tail(const cffm_shape_t* s, const int32_t* ids, int32_t B, void* ws,
     return 0;
 }
 
+// An id outside [0, M) is keyed as M: the radix sorts look at ceil(log2(M + 1)) id bits only, and a raw bad id whose low
+// bits equal a valid id would land inside that id's run and split its segment in two (two wavefronts updating one row).
+// All bad ids form ONE segment with id M, which every update kernel skips (id >= M).
 __global__ __launch_bounds__(256) void pack_keys_kernel(const int32_t* __restrict__ ids, unsigned long long* keys, int64_t n,
-                                                        int64_t id_stride) {
+                                                        int64_t id_stride, int M) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = ((unsigned long long)(unsigned)ids[i * id_stride] << 32) | (unsigned long long)i;
+    if (i < n) {
+        const int raw = ids[i * id_stride];
+        keys[i] = ((unsigned long long)(unsigned)((raw < 0 || raw >= M) ? M : raw) << 32) | (unsigned long long)i;
+    }
 }
 
 #include "sort_body.hpp"
@@ -365,10 +371,10 @@ int cffm_sort_keys_impl(const cffm_shape_t* s, const int32_t* ids, int64_t n_row
     void* tmp = (void*)(w + wl.sort_tmp);
     size_t tmp_bytes = 0;
     int bits = 1;
-    while ((1ll << bits) < (long long)s->M && bits < 31) ++bits;
+    while ((1ll << bits) <= (long long)s->M && bits < 31) ++bits;      // ids 0 .. M (M = the key of every out-of-range id)
     // slots are unique, so sorting the packed keys IS the stable sort by id with slots ascending inside a segment
     if (!prepacked) {
-        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ids, keys_in, n_rows, id_stride);
+        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, ids, keys_in, n_rows, id_stride, s->M);
         CFFM_CHECK_LAUNCH();
     }
     if (n_rows <= 4096) {                       // one workgroup, one launch

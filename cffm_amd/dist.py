@@ -23,6 +23,7 @@ over the GLOBAL batch, CFFM.py:493) and the parameter gradients:
 ``compute`` is any object with the HipEngine step-half interface (forward / backward / apply_dense /
 apply_sparse + the tensors named below); the CPU tests plug the oracle in there, the product uses HipEngine.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -290,3 +291,45 @@ class ShardedStep(object):
         rows = c.pack_rows_dedup(plan.local_ids, plan.order, plan.uniq, B)
         recv = self._a2a(rows[:u], sc, rc)
         return c.dp_apply(grad, recv, Bg)
+
+
+# ---- checkpoint of a row-sharded model ("sharded-table aware") ----------------------------------------------
+# Every rank writes its own shard of the three tables and of their optimizer slots (local rows rank, rank + G, ...); the
+# replicated dense parameters (identical on every rank) are written by rank 0 only.  Plain tensors: weights_only loads.
+def save_sharded(engine, path, rank, world, opt_step=0):
+    t = lambda d, keys: {k: torch.from_numpy(d[k].copy()) for k in keys}
+    tables = ('inner_embeddings', 'outer_embeddings', 'feature_bias')
+    params, accs = engine.export_params(), engine.export_accumulators()
+    second = engine.export_second_moments() if hasattr(engine, 'export_second_moments') else None
+    blob = {'format': 2, 'rank': int(rank), 'world': int(world), 'local_rows': int(params['inner_embeddings'].shape[0]),
+            'tables': t(params, tables), 'table_slots': t(accs, tables),
+            'table_slots2': t(second, tables) if second is not None else None, 'opt_step': int(opt_step)}
+    if rank == 0:
+        dense = [k for k in params if k not in tables]
+        blob['dense'] = t(params, dense)
+        blob['dense_slots'] = t(accs, [k for k in dense if k in accs])
+        blob['dense_slots2'] = t(second, [k for k in dense if k in second]) if second is not None else None
+    torch.save(blob, '%s.shard%d-of-%d.pt' % (path, rank, world))
+
+
+def load_sharded(engine, path, rank, world):
+    """Restores what save_sharded wrote at the SAME world size (a shard holds rows r with r % world == rank)."""
+    own = torch.load('%s.shard%d-of-%d.pt' % (path, rank, world), weights_only=True)
+    if own['world'] != world or own['rank'] != rank:
+        raise ValueError('shard file written for rank %d of %d' % (own['rank'], own['world']))
+    root = own if rank == 0 else torch.load('%s.shard0-of-%d.pt' % (path, world), weights_only=True)
+    n = lambda d: {k: v.numpy() for k, v in d.items()}
+    params, accs = n(root['dense']), n(root['dense_slots'])
+    params.update(n(own['tables']))
+    accs.update(n(own['table_slots']))
+    second = None
+    if own.get('table_slots2') is not None:
+        second = n(root['dense_slots2'])
+        second.update(n(own['table_slots2']))
+    if params['inner_embeddings'].shape[0] != engine.cfg.M:
+        raise ValueError('shard has %d local rows, this engine owns %d' % (params['inner_embeddings'].shape[0], engine.cfg.M))
+    for k, v in engine.export_params().items():          # untrained reference variables kept on the host only
+        params.setdefault(k, v)
+        accs.setdefault(k, np.zeros_like(v))
+    engine.load_params(params, accs, second)
+    return int(own.get('opt_step', 0))

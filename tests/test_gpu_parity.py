@@ -883,3 +883,39 @@ def test_empty_batch_is_a_no_op():
     after = eng.export_params()
     for k, v in before.items():
         np.testing.assert_array_equal(v, after[k])
+
+
+@pytest.mark.parametrize('B', [64, 1024])
+def test_out_of_range_ids_do_not_split_a_segment(B):
+    """A bad id (outside [0, M)) is read as a clamped row by the gather and skipped by the update.  Its LOW bits may equal
+    a valid id: the radix sorts of the sparse update look at ceil(log2(M + 1)) id bits only, so it must not land inside
+    that id's run (two wavefronts would then update one row).  Property: the step with bad ids equals, bit for bit and on
+    every row but the clamp row M - 1, the step where those slots carry M - 1 instead.  B = 64: single-launch forward with
+    keys placed by counting rank; B = 1024: 10,240 lookups, rocPRIM radix sort."""
+    cfg, p32, _, _ = make_case('frappe-selu')
+    rng = np.random.default_rng(2)
+    X = rng.integers(0, cfg.M - 1, size=(B, cfg.F)).astype(np.int32)
+    y = rng.choice([-1.0, 1.0], size=(B,)).astype(np.float32)
+    X[:, 0] = 37                                       # a long segment of a valid id
+    bad_lo = (1 << int(np.ceil(np.log2(cfg.M + 1)))) + 37          # low bits == 37
+    Xa, Xb = X.copy(), X.copy()
+    slots = [(3, 1), (B // 2, 4), (B - 1, 9), (5, 2)]
+    for (b, f), v in zip(slots, (bad_lo, -7, bad_lo + (1 << 20), cfg.M)):
+        Xa[b, f] = v
+        Xb[b, f] = cfg.M - 1 if v >= 0 else 0          # what the gather reads for it
+    ea, eb = engine_for(cfg, p32), engine_for(cfg, p32)
+    yt = torch.from_numpy(y).cuda()
+    la = ea.train_step(torch.from_numpy(Xa).cuda(), yt).clone()
+    lb = eb.train_step(torch.from_numpy(Xb).cuda(), yt).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb)
+    keep = np.ones(cfg.M, dtype=bool)
+    keep[[0, cfg.M - 1]] = False                       # the two clamp rows receive the bad slots' gradients in run B only
+    pa, pb = ea.export_params(), eb.export_params()
+    aa, ab = ea.export_accumulators(), eb.export_accumulators()
+    for k in pa:
+        if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+            np.testing.assert_array_equal(pa[k][keep], pb[k][keep], err_msg=k)
+            np.testing.assert_array_equal(aa[k][keep], ab[k][keep], err_msg='acc ' + k)
+        else:
+            np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
