@@ -859,9 +859,10 @@ extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
 // whose rows lie beyond m_hi only helps staging the filter and keeps the barriers.
 // inL / outL (fused forward only): LDS copies of this example's input / output activations, [rows][PP], rows counted
 // from m_base; the A operand then never touches global memory and the output is left where the next phase reads it.
-template <int NT, int RM, bool GEN, int G = 1>
+template <int NT, int RM, bool GEN, int G = 1, int ACTC = -1>
 __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0_wg, int64_t m_hi, char* smem,
                                                    const float* inL = nullptr, float* outL = nullptr, int64_t m_base = 0) {
+    const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
     constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
     float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
@@ -934,8 +935,8 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
         for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
             for (int h = 0; h < NT; ++h) {
-                av[rm][h].x = act_pos(av[rm][h].x, a.act); av[rm][h].y = act_pos(av[rm][h].y, a.act);
-                av[rm][h].z = act_pos(av[rm][h].z, a.act); av[rm][h].w = act_pos(av[rm][h].w, a.act);
+                av[rm][h].x = act_pos(av[rm][h].x, act); av[rm][h].y = act_pos(av[rm][h].y, act);
+                av[rm][h].z = act_pos(av[rm][h].z, act); av[rm][h].w = act_pos(av[rm][h].w, act);
             }
     }
     PHASE_MARK2(2);
@@ -1296,7 +1297,9 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
 
 // NW wavefronts per workgroup (8 at the README shapes): one example still owns one workgroup, but every SIMD now has
 // two wavefronts to switch between, which is what hides the LDS / MFMA / L2 latencies of the per-example phases.
-template <int NT, int NW>
+// ACT >= 0: the activation id compiled in (selu / elu / relu of the three README commands): the act switches of the inner
+// branch, of the A operands of the conv layers and of the pooling sweep fold into straight code
+template <int NT, int NW, int ACT = -1>
 __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
     constexpr int G = NW / 4, PP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
         if (b != (int)blockIdx.x) __syncthreads();
         if (fa.rank_keys) rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
         PHASE_MARK(0);
-        inner_fwd_body(fa.inner, b, smem);                 // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
+        inner_fwd_body<ACT>(fa.inner, b, smem);            // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
         if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1);
         conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem, CL[0]);   // reads Eo[b], writes C_0[b]
@@ -1325,17 +1328,17 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
             if (rows >= 64) {
                 for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
                     if (m0 > m_lo) lds_barrier();
-                    conv_fwd_taps_body<NT, 4 / G, false, G>(ca, m0, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                    conv_fwd_taps_body<NT, 4 / G, false, G, ACT>(ca, m0, m_hi, smem, CL[l - 1], CL[l], m_lo);
                 }
             } else if (rows >= 32) {
-                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G, ACT>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
             } else {
-                conv_fwd_taps_body<NT, 1, false, G>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                conv_fwd_taps_body<NT, 1, false, G, ACT>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
             }
         }
         if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1 + fa.live);
-        head_fwd_body<NW>(fa.head, b, smem, lds_act ? CL : nullptr);
+        head_fwd_body<NW, ACT>(fa.head, b, smem, lds_act ? CL : nullptr);
         PHASE_MARK(2 + fa.live);
     }
 #ifdef CFFM_PHASE_TIMERS
@@ -1637,8 +1640,9 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 // the field, in pair order: bitwise reproducible, and ~100x cheaper than ds_add_f32 (measured: the atomic
 // version spent 83 K LDS cycles per CU).
 // m_lo / m_end (fused top-of-backward kernel): the tiles start at m_lo and rows >= m_end are masked instead of a.Mtot
-template <int NT, int RM, bool L0, int HALVES>
+template <int NT, int RM, bool L0, int HALVES, int ACTC = -1>
 __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem, int64_t m_lo = 0, int64_t m_end = -1) {
+    const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, BM = 16 * RM, NTH = 256 * HALVES, NCOPY = 4 * HALVES;
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]
@@ -1749,7 +1753,7 @@ __device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char
                     for (int j = 0; j < 4; ++j) {
                         if (mrow + j < Mend) {
                             const float g = acc[rm][nt][j] + dpre[L0 ? 0 : rm][j];
-                            a.dprev[ppos[L0 ? 0 : rm][j] + nt * 16] = g * act_relu_grad(cpre[L0 ? 0 : rm][L0 ? 0 : nt][j], a.act);
+                            a.dprev[ppos[L0 ? 0 : rm][j] + nt * 16] = g * act_relu_grad(cpre[L0 ? 0 : rm][L0 ? 0 : nt][j], act);
                         }
                     }
                 } else {
@@ -1873,9 +1877,10 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 // loads from L2, or, for layer 0, generated from the embedding tiles held in LDS.  With HALVES = 2 the
 // sub-chunk is cut in two and the two partial blocks of a tap are added (lower half first) through LDS.
 #define WGT_SUB 256
-template <int NT, bool GEN, int HALVES>
+template <int NT, bool GEN, int HALVES, int ACTC = -1>
 __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, int nslab, char* smem, int64_t m_lo_o = -1,
                                                 int64_t m_hi_o = -1) {
+    const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
     float* Bs = reinterpret_cast<float*>(smem);               // [WGT_SUB][PP]
     uint32_t* lut = reinterpret_cast<uint32_t*>(Bs + WGT_SUB * PP);   // GEN: [PP]
@@ -1962,7 +1967,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, in
                         for (int q = 0; q < NT; ++q) bs[q] += bv[q];
 #pragma unroll
                         for (int i = 0; i < NT; ++i) {
-                            const float x = GEN ? av[u][i] : act_pos(av[u][i], a.act);
+                            const float x = GEN ? av[u][i] : act_pos(av[u][i], act);
 #pragma unroll
                             for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(x, bv[q], acc[i][q]);
                         }
@@ -2033,13 +2038,13 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
 // one launch, one cold-cache ramp and one drain less per layer.  The top layer's launch can also carry the backward
 // of the inner branch (n_i workgroups, first in dispatch order: the longest role), which depends on dL/dout only
 // and would otherwise sit on a mostly idle chip while the small top layers run.
-template <int NT, int RM>
+template <int NT, int RM, int ACT = -1>
 __global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
-    if (bid < n_i) inner_bwd_body(ib, bid, n_i, smem);
-    else if (bid < n_i + n_d) dgrad_taps_body<NT, RM, false, 1>(d, bid - n_i, smem);
-    else wgrad_taps_body<NT, false, 1>(w, bid - n_i - n_d, n_w, smem);
+    if (bid < n_i) inner_bwd_body<ACT>(ib, bid, n_i, smem);
+    else if (bid < n_i + n_d) dgrad_taps_body<NT, RM, false, 1, ACT>(d, bid - n_i, smem);
+    else wgrad_taps_body<NT, false, 1, ACT>(w, bid - n_i - n_d, n_w, smem);
 }
 
 // Top of the backward in ONE launch (B <= 256, Pp <= 64): workgroup b runs, for example b, the head backward and then
@@ -2059,7 +2064,7 @@ struct BwdTopArgs {
     int n_rows;
 };
 
-template <int NT>
+template <int NT, int ACT = -1>
 __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float dh1s[CFFM_HEAD_UNITS];
@@ -2072,7 +2077,7 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
         if (a.rank_ids != nullptr) {
             for (int b = bid; b < a.hb.B; b += a.n_inner) rank_keys_body<4>(a.rank_ids, a.n_rows, b, a.hb.g.F, a.keys_sorted, smem);
         }
-        inner_bwd_body(a.ib, bid, a.n_inner, smem, L);
+        inner_bwd_body<ACT>(a.ib, bid, a.n_inner, smem, L);
         return;
     }
     const int b = bid - a.n_inner;                           // ---- role 2: example b (also slab b of every range)
@@ -2080,14 +2085,14 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
     head_bwd_begin(a.hb, b, st);
     const float L = head_bwd_loss(a.hb, b == 0, red);
     if (b < a.hb.B)
-        head_bwd_example(a.hb, b, st, b, head_dout(a.hb.loss, a.hb.out[b], a.hb.y[b], 1.f / (float)a.hb.Bg, L), dh1s, dt1s);
+        head_bwd_example<ACT>(a.hb, b, st, b, head_dout(a.hb.loss, a.hb.out[b], a.hb.y[b], 1.f / (float)a.hb.Bg, L), dh1s, dt1s);
     head_bwd_end(a.hb, b, st);
     for (int t = 0; t < a.n_layers; ++t) {
         __syncthreads();                                     // dC of this layer (global, written above) is complete
         const int64_t rows = 1ll << (2 * a.lgSo[t]);
         const int64_t m_lo = (int64_t)b * rows, m_hi = b < a.hb.B ? m_lo + rows : m_lo;
-        wgrad_taps_body<NT, false, 1>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
-        for (int64_t m0 = m_lo; m0 < m_hi; m0 += 16) dgrad_taps_body<NT, 1, false, 1>(a.d[t], 0, smem, m0, m_hi);
+        wgrad_taps_body<NT, false, 1, ACT>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
+        for (int64_t m0 = m_lo; m0 < m_hi; m0 += 16) dgrad_taps_body<NT, 1, false, 1, ACT>(a.d[t], 0, smem, m0, m_hi);
     }
 }
 
@@ -2796,10 +2801,19 @@ static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl,
     InnerBwdArgs none;
     memset(&none, 0, sizeof(none));
     if (ib && inner_bwd_lds(ib->g) > lds) lds = inner_bwd_lds(ib->g);
-    int rc = set_lds(conv_bwd_pair_kernel<NT, RM>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM>), dim3(n_d + nsl + (ib ? n_i : 0)), dim3(256), lds, st, d, w, n_d, nsl,
-                       ib ? *ib : none, ib ? n_i : 0);
+    // activation compiled in for the README commands (see launch_fwd_all)
+#define PAIR_GO(ACT_)                                                                                                          \
+    do {                                                                                                                        \
+        int rc_ = set_lds(conv_bwd_pair_kernel<NT, RM, ACT_>, lds);                                                             \
+        if (rc_) return rc_;                                                                                                    \
+        hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM, ACT_>), dim3(n_d + nsl + (ib ? n_i : 0)), dim3(256), lds, st, d, w, n_d, \
+                           nsl, ib ? *ib : none, ib ? n_i : 0);                                                                 \
+    } while (0)
+    if (NT == 3 && d.act == CFFM_ACT_SELU) PAIR_GO(CFFM_ACT_SELU);
+    else if (NT == 1 && d.act == CFFM_ACT_ELU) PAIR_GO(CFFM_ACT_ELU);
+    else if (NT == 1 && d.act == CFFM_ACT_RELU) PAIR_GO(CFFM_ACT_RELU);
+    else PAIR_GO(-1);
+#undef PAIR_GO
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -2898,9 +2912,18 @@ static void fill_taps_bwd_args(const cffm_shape_t* s, const float* theta, void* 
 
 template <int NT>
 static int launch_bwd_top(const BwdTopArgs& a, size_t lds, hipStream_t st) {
-    int rc = set_lds(bwd_top_kernel<NT>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((bwd_top_kernel<NT>), dim3(a.n_inner + 256), dim3(256), lds, st, a);
+    const int act = a.hb.g.act;
+#define TOP_GO(ACT_)                                                                                          \
+    do {                                                                                                       \
+        int rc_ = set_lds(bwd_top_kernel<NT, ACT_>, lds);                                                      \
+        if (rc_) return rc_;                                                                                   \
+        hipLaunchKernelGGL((bwd_top_kernel<NT, ACT_>), dim3(a.n_inner + 256), dim3(256), lds, st, a);          \
+    } while (0)
+    if (NT == 3 && act == CFFM_ACT_SELU) TOP_GO(CFFM_ACT_SELU);
+    else if (NT == 1 && act == CFFM_ACT_ELU) TOP_GO(CFFM_ACT_ELU);
+    else if (NT == 1 && act == CFFM_ACT_RELU) TOP_GO(CFFM_ACT_RELU);
+    else TOP_GO(-1);
+#undef TOP_GO
     CFFM_CHECK_LAUNCH();
     return 0;
 }
@@ -3105,9 +3128,20 @@ bool cffm_fwd_all_ok(const cffm_shape_t* s, int32_t B) {
 template <int NT>
 static int launch_fwd_all(const FwdAllArgs& fa, size_t lds, hipStream_t st) {
     constexpr int NW = 8;
-    int rc = set_lds(fwd_all_kernel<NT, NW>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((fwd_all_kernel<NT, NW>), dim3(fa.B < 256 ? fa.B : 256), dim3(64 * NW), lds, st, fa);
+    // the three README commands get their activation compiled in: frappe = selu at Pp 48, ml-tag = elu and book-crossing =
+    // relu at Pp 16 (README.md:20-28)
+    const int act = fa.inner.g.act;
+#define FWD_ALL_GO(ACT_)                                                                                              \
+    do {                                                                                                               \
+        int rc_ = set_lds(fwd_all_kernel<NT, NW, ACT_>, lds);                                                          \
+        if (rc_) return rc_;                                                                                           \
+        hipLaunchKernelGGL((fwd_all_kernel<NT, NW, ACT_>), dim3(fa.B < 256 ? fa.B : 256), dim3(64 * NW), lds, st, fa); \
+    } while (0)
+    if (NT == 3 && act == CFFM_ACT_SELU) FWD_ALL_GO(CFFM_ACT_SELU);
+    else if (NT == 1 && act == CFFM_ACT_ELU) FWD_ALL_GO(CFFM_ACT_ELU);
+    else if (NT == 1 && act == CFFM_ACT_RELU) FWD_ALL_GO(CFFM_ACT_RELU);
+    else FWD_ALL_GO(-1);
+#undef FWD_ALL_GO
     CFFM_CHECK_LAUNCH();
     return 0;
 }

@@ -37,8 +37,9 @@ static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFF
 // NW wavefronts: the pooling sweeps, the embedding tile and s0 use all of them; the dense(32) partials stay on the
 // first 256 threads (8 parts x 32 units)
 // CL != nullptr (fused forward): LDS copies of this example's conv outputs, read instead of the global ones
-template <int NW = 4>
+template <int NW = 4, int ACTC = -1>
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem, float* const* CL = nullptr) {
+    const int act = ACTC >= 0 ? ACTC : a.g.act;         // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int NTH = 64 * NW, RPW = 16 / NW;                    // rows per wave in one pooling sweep
     float* t1s = reinterpret_cast<float*>(smem);                   // [1024]
     float (*hpart)[CFFM_HEAD_UNITS] = reinterpret_cast<float (*)[CFFM_HEAD_UNITS]>(t1s + 1024);   // [8][32]
@@ -126,7 +127,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
                         const int yy = y0 + NW * u;
                         if (yy < S) {
                             const float4 v = base[(int64_t)yy * n4 + i];
-                            s4[u] += (act_pos(v.x, g.act) + act_pos(v.y, g.act)) + (act_pos(v.z, g.act) + act_pos(v.w, g.act));
+                            s4[u] += (act_pos(v.x, act) + act_pos(v.y, act)) + (act_pos(v.z, act) + act_pos(v.w, act));
                         }
                     }
                 }
@@ -275,6 +276,7 @@ __device__ __forceinline__ float head_bwd_loss(const HeadBwdArgs& a, bool publis
 }
 
 // dh1s [CFFM_HEAD_UNITS] and dt1s [2D-2] are LDS scratch of the caller
+template <int ACTC = -1>
 __device__ __forceinline__ void head_bwd_example(const HeadBwdArgs& a, int slab, HeadBwdState& st, int b, float d,
                                                  float* dh1s, float* dt1s) {
     const Geo& g = a.g;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void head_bwd_example(const HeadBwdArgs& a, int slab,
         for (int e = tid; e < ntop; e += 256) {
             const int yy = e / (2 * g.Pp);
             const int64_t idx = (int64_t)b * ntop + e;
-            a.dCtop[idx] = dt1s[off_top + yy] * act_relu_grad(a.Ctop[idx], g.act);
+            a.dCtop[idx] = dt1s[off_top + yy] * act_relu_grad(a.Ctop[idx], ACTC >= 0 ? ACTC : g.act);
         }
     }
     if (wave == 0) {

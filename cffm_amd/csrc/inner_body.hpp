@@ -45,8 +45,11 @@ struct InnerFwdArgs {
 };
 static inline size_t inner_fwd_lds(const Geo& g) { return (size_t)(g.F * g.K + g.Pp + 16) * 4; }   // + up to 16 wavefront partials
 
+// ACTC >= 0: the activation id as a compile-time constant (the README shapes): every act switch folds away
+template <int ACTC = -1>
 __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, char* smem) {
     const Geo& g = ia.g;
+    const int act = ACTC >= 0 ? ACTC : g.act;
     const float* Ei = ia.Ei; const float* cw_g = ia.cw; const float* cb_g = ia.cb; const float* wd = ia.wd;
     const float* bd = ia.bd; float* inner_out = ia.inner_out; const FusedGather& fg = ia.fg;
     float* E = reinterpret_cast<float*>(smem);                                   // [F*K]
@@ -89,7 +92,7 @@ __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, ch
     float part = 0.f;
     for (int u = threadIdx.x; u < units; u += blockDim.x) {
         const int p = fast_div(u, invK2), t = u - p * K2;
-        const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, g.act);
+        const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, act);
         const float2 w2 = *reinterpret_cast<const float2*>(&wd[(int64_t)p * g.K + 2 * t]);   // flat index p*K + t*2 + ch (:333)
         part += v.s0 * w2.x + v.s1 * w2.y;
     }
@@ -114,8 +117,10 @@ struct InnerBwdArgs {
 };
 static inline size_t inner_bwd_lds(const Geo& g) { return (size_t)(5 * g.F * g.K + g.Pp + 8) * 4; }
 
+template <int ACTC = -1>
 __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, int nslab, char* smem, float L = 1.f) {
     const Geo& g = a.g;
+    const int act = ACTC >= 0 ? ACTC : g.act;            // ACTC >= 0: compile-time activation id (README shapes)
     const int B = a.B;
     const float* __restrict__ Ei = a.Ei; const float* __restrict__ dout = a.dout;
     const float* __restrict__ cw_g = a.cw; const float* __restrict__ cb_g = a.cb; const float* __restrict__ wd = a.wd;
@@ -148,7 +153,7 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
         float* myE = dE + wave * FK;
         for (int u = threadIdx.x; u < units; u += blockDim.x) {
             const int p = fast_div(u, invK2), t = u - p * K2;
-            const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, g.act);
+            const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, act);
             const int64_t wi = (int64_t)p * g.K + 2 * t;
             const float2 w2 = *reinterpret_cast<const float2*>(&wd[wi]);
             // dense(1) kernel gradient: flat * dout
@@ -156,15 +161,15 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
             acc2.x += v.s0 * db; acc2.y += v.s1 * db;
             *reinterpret_cast<float2*>(&slab_dw[wi]) = acc2;
             const float ds0 = db * w2.x, ds1 = db * w2.y;
-            const float dz0 = ds0 * act_relu_grad(fmaxf(v.z0, 0.f), g.act);
-            const float dz1 = ds1 * act_relu_grad(fmaxf(v.z1, 0.f), g.act);
+            const float dz0 = ds0 * act_relu_grad(fmaxf(v.z0, 0.f), act);
+            const float dz1 = ds1 * act_relu_grad(fmaxf(v.z1, 0.f), act);
             gcw[0] += dz0 * v.x0; gcw[1] += dz1 * v.x0; gcw[2] += dz0 * v.x1; gcw[3] += dz1 * v.x1;
             gcb[0] += dz0; gcb[1] += dz1;
             const float dmp = ds0 + ds1;
             const bool firstmax = v.x0 >= v.x1;                       // max-pool grad: first element on ties
             const float dx0 = dz0 * cw[0] + dz1 * cw[1] + (firstmax ? dmp : 0.f);
             const float dx1 = dz0 * cw[2] + dz1 * cw[3] + (firstmax ? 0.f : dmp);
-            const float dI0 = dx0 * act_grad_f(v.I0, g.act), dI1 = dx1 * act_grad_f(v.I1, g.act);
+            const float dI0 = dx0 * act_grad_f(v.I0, act), dI1 = dx1 * act_grad_f(v.I1, act);
             atomicAdd(&myE[v.i * g.K + 2 * t], dI0 * v.ejx);
             atomicAdd(&myE[v.i * g.K + 2 * t + 1], dI1 * v.ejy);
             atomicAdd(&myE[v.j * g.K + 2 * t], dI0 * v.eix);
