@@ -9,6 +9,10 @@ CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unu
 ifdef PHASE_TIMERS
 CXXFLAGS += -DCFFM_PHASE_TIMERS
 endif
+# debug build only: CFFM_DBG=<bits> skips phases of the tiled layer-0 kernels (tools/dbg_tile.py)
+ifdef TILE_DBG
+CXXFLAGS += -DCFFM_TILE_DBG
+endif
 
 PYEXT := $(OUT)/_cffm_pybind$(shell python3-config --extension-suffix)
 

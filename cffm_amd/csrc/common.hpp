@@ -7,6 +7,20 @@
 
 #define CFFM_WAVE 64
 
+#ifdef CFFM_PHASE_TIMERS
+// debug build only (make PHASE_TIMERS=1, tools/phase.py): 100 MHz timestamps of workgroup 7's phase boundaries inside the
+// fused forward launch (slots 0-7), and of the sub-phases of its head phase (slots 8-15)
+static __device__ unsigned long long cffm_phase_times[16];
+static __device__ unsigned long long cffm_wg_times[2 * 1024];
+#define PHASE_MARK(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[i] = wall_clock64(); } while (0)
+#define PHASE_MARK2(i) do {} while (0)
+#define PHASE_MARK3(i) do { if (CL != nullptr && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PHASE_MARK(i) do {} while (0)
+#define PHASE_MARK2(i) do {} while (0)
+#define PHASE_MARK3(i) do {} while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CFFM_CHECK_LAUNCH()                          \

@@ -19,6 +19,7 @@
 // uses the same k permutation, which the contraction does not care about.
 // Channels are padded to Pp = ceil16(P) in every activation tensor so that 16-byte pieces never
 // straddle a row and tiles never straddle a filter tap; padded channels hold zeros.
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.hpp"
@@ -183,6 +184,7 @@ struct ConvArgs {
     int64_t Mtot;        // B*So*So
     int B, lgSo, P, Pp, F, D, act;
     int nblk;            // conv_fwd_kernel: column blocks of a row tile (the grid is 1-D, see xcd_tile)
+    int dbg;             // debug build only (make TILE_DBG=1): phase-skipping bits for tools/dbg_tile.py, 0 otherwise
 };
 
 template <int NT, int RM, bool GEN>
@@ -839,20 +841,12 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgradArgs a) {
 // =================================================================================================
 // rows [m0, m0 + 16*RM) clipped to m_hi (the fused forward kernel passes the rows of ONE example)
 #ifdef CFFM_PHASE_TIMERS
-// debug build only (make PHASE_TIMERS=1): 100 MHz timestamps of workgroup 7's phase boundaries
-__device__ unsigned long long cffm_phase_times[16];
-__device__ unsigned long long cffm_wg_times[2 * 1024];
-#define PHASE_MARK(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[i] = wall_clock64(); } while (0)
-#define PHASE_MARK2(i) do { if (a.lgSo == 3 && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
 extern "C" int cffm_debug_wg_times(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cffm_wg_times), sizeof(cffm_wg_times));
 }
 extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
     return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(cffm_phase_times), sizeof(cffm_phase_times));
 }
-#else
-#define PHASE_MARK(i) do {} while (0)
-#define PHASE_MARK2(i) do {} while (0)
 #endif
 
 // G groups of four tap-wavefronts (G = 1: 256 threads): group g takes the RM row tiles starting at m0 + g*16*RM; a group
@@ -2245,12 +2239,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
     int bid = blockIdx.x;
     const int b = bid % a.B; bid /= a.B;
     const int xt = bid % RT, qt = bid / RT, q0 = qt * 16, x0 = xt * 16;
+#ifdef CFFM_TILE_DBG
+    const int dbg = a.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     {
         const float* e = a.in + (int64_t)b * F * D;
         const float invD = 1.f / (float)D;
         for (int i = tid; i < F * D; i += NTH) {
             const int f = fast_div(i, invD), d = i - f * D;
-            Es[f * Dp + d] = e[i];
+            Es[f * Dp + d] = (dbg & 16) ? 1.f : e[i];
         }
     }
     lds_barrier();
@@ -2267,12 +2266,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
             const int k = 4 * ks + kk;                          // 16 independent L2 loads and 16 independent LDS reads
             const bool ok = k < K;
             const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
-            bw[ks] = ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f;
+            bw[ks] = (dbg & 2) ? 1.f : (ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f);
             av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
         }
         // (measured at F32 D64: unconditional chains of 16/8 or 16/12/8/4 MFMAs ran this kernel 8 % and 20 % SLOWER than
         // the test per k-step below - the forward has one unit per wave and step, so the skipped MFMAs are what counts)
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 4))
 #pragma unroll
         for (int ks = 0; ks < C0T_MAXKS; ++ks)
             if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);  // wave-uniform skip of the empty k-steps
@@ -2294,7 +2294,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
         f32x4 acc[XQ];
 #pragma unroll
         for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s2 = 0; s2 < ks2; ++s2) {
+        for (int s2 = 0; s2 < ((dbg & 8) ? 0 : ks2); ++s2) {
             const int k = 4 * s2 + kk;
             const bool ok = k < K2;
             const int dh = (ok && k >= F) ? 1 : 0, i = ok ? k - dh * F : 0;
@@ -2308,7 +2308,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int yy = rt * 16 + kk * 4 + j;
-                a.out[(((int64_t)b * S + yy) * S + x0 + xg + q4) * PpT + q0 + r] = fmaxf(acc[q4][j] + bias, 0.f);
+                const float c = fmaxf(acc[q4][j] + bias, 0.f);
+                if (!(dbg & 1) || c == 12345.678f)
+                    a.out[(((int64_t)b * S + yy) * S + x0 + xg + q4) * PpT + q0 + r] = c;
             }
     }
 }
@@ -2694,7 +2696,13 @@ static int launch_conv0_fact_tile_fwd(const ConvArgs& a, hipStream_t st) {
     if (rc) return rc;
     const int64_t grid = (int64_t)a.B * (a.Pp / 16) * (S / 16);
     if (grid > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+#ifdef CFFM_TILE_DBG
+    ConvArgs b = a;
+    b.dbg = getenv("CFFM_DBG") ? atoi(getenv("CFFM_DBG")) : 0;
+    hipLaunchKernelGGL((conv0_fact_tile_fwd_kernel<NW>), dim3((unsigned)grid), dim3(64 * NW), lds, st, b);
+#else
     hipLaunchKernelGGL((conv0_fact_tile_fwd_kernel<NW>), dim3((unsigned)grid), dim3(64 * NW), lds, st, a);
+#endif
     CFFM_CHECK_LAUNCH();
     return 0;
 }

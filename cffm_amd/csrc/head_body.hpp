@@ -46,11 +46,12 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     float* rs = t1s + 1024 + 8 * CFFM_HEAD_UNITS;                  // [CFFM_MAX_FIELDS]
     float* sc = rs + CFFM_MAX_FIELDS;                              // [4]
     float* Et = sc + 4;                                            // [F][D] embedding tile of this example
-    float* aW = Et + a.g.F * a.g.D;                                // [F][F] attention matrix, staged and used by wave 1 only
+    float* aW = Et + a.g.F * a.g.D;                                // [F][F] attention matrix, staged and used by one wave only
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t1w = 2 * g.D - 2;
     const int q = tid & 31, part = tid >> 5, kpp = (t1w + 7) / 8;
+    PHASE_MARK3(0);
     // ---- phase 0: independent loads ------------------------------------------------------------------------
     float w1r[HEAD_KPP];
     const bool pre = a.outer_conv && kpp <= HEAD_KPP;
@@ -63,7 +64,10 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
     }
     // every scalar / per-lane parameter of the later phases is requested now, so that no phase waits on L2 again
     float fbv = 0.f, attb = 0.f, linw = 0.f, linb = 0.f, d1b = 0.f, d2w = 0.f, d2b = 0.f, io = 0.f, biasv = 0.f, yv = 0.f;
-    if (wave == 1) {
+    // the first-order term runs on the LAST wavefront: the first ones carry the pooling rows of the small top layers, and
+    // the barrier behind the pools waited 1.9 us for wave 1 when it did both (phase timers, frappe)
+    constexpr int FO = NW - 1;
+    if (wave == FO) {
         if (lane < g.F) {
             fbv = a.fb[(int64_t)b * g.F + lane];
             linw = g.linear_att ? a.lin_w[lane] : 0.f;
@@ -87,7 +91,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
         for (int i = tid; i < g.F * g.D / 4; i += NTH) reinterpret_cast<float4*>(Et)[i] = E4[i];
     }
-    if (wave == 1) {                                                 // first-order term, :422-446 (needs nothing from the other waves)
+    if (wave == FO) {                                                // first-order term, :422-446 (needs nothing from the other waves)
         float lin;
         if (g.linear_att) {
             float z = attb;
@@ -107,6 +111,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         }
         if (lane == 0) sc[1] = lin;
     }
+    PHASE_MARK3(1);
     float o = 0.f;
     if (a.outer_conv) {
         // pools of the live layers: s_{l+1}[y] = sum_{x,q} act(C_l[b,y,x,q])                      (:390-391)
@@ -139,7 +144,9 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             }
             off += S;
         }
+        PHASE_MARK3(2);
         lds_barrier();                                             // Et (and the pools) are in LDS
+        PHASE_MARK3(3);
         for (int f = wave; f < g.F; f += NW) {                      // row sums of the embedding tile
             float s = 0.f;
             for (int d = lane; d < g.D; d += 64) s += Et[f * g.D + d];
@@ -157,6 +164,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             t1s[h] = s;
         }
         lds_barrier();
+        PHASE_MARK3(4);
         for (int k = tid; k < t1w; k += NTH) a.t1[(int64_t)b * t1w + k] = t1s[k];
         if (tid < 256) {                                             // dense(32), :409: 8 partial sums per unit
             float s = 0.f;
@@ -172,6 +180,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             hpart[part][q] = s;
         }
         lds_barrier();
+        PHASE_MARK3(5);
         if (wave == 0) {                                             // + bias, then dense(1) * beta, :410, :414
             float h = 0.f;
             if (lane < CFFM_HEAD_UNITS) {
@@ -185,6 +194,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             if (lane == 0) sc[0] = g.beta_outer * (v + d2b);
         }
     }
+    PHASE_MARK3(6);
     lds_barrier();
     if (tid == 0) {
         if (a.outer_conv) o = sc[0];

@@ -20,9 +20,9 @@ for i in range(10):
     hip.load().cffm_debug_phase_times(buf)
     t = np.array(list(buf), dtype=np.int64)[:8]
     rows.append(np.diff(t) * 10)       # ns
-    t2 = np.array(list(buf), dtype=np.int64)[8:14]
+    t2 = np.array(list(buf), dtype=np.int64)[8:15]
     rows2 = globals().setdefault('rows2', []); rows2.append(np.diff(t2) * 10)
 print('phases (ns): inner+gather, conv0, conv1, conv2, conv3, head')
 print(np.median(np.array(rows), axis=0), 'total', np.median(np.array(rows).sum(axis=1)))
-print('conv1 sub-phases (ns): loads+Wstage+sync, (act), ->mfma start, mfma, sync, reduce+write')
+print('head sub-phases (ns): independent loads + first-order term, pooling sweeps, barrier, row sums + s0, t1 + dense32, dense1, (last barrier)')
 print(np.median(np.array(rows2), axis=0))
