@@ -2254,28 +2254,53 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
     }
     lds_barrier();
     // ---- step 1 -----------------------------------------------------------------------------------------------------
+    // The kernel is instruction-issue-bound (with every load, MFMA and store switched off it still ran 11.6 of its 29.2 ms
+    // at F32 D64: tools/dbg_tile.py), and most of those instructions were the per-unit operand bookkeeping.  So the k index
+    // runs over ALL fields, k = dw * F4 + j (F4 = F rounded up to 4): the E fragment of a k-step then does not depend on the
+    // unit (16 LDS reads per WAVE instead of per unit), the W fragment is one load at a lane-constant offset from a
+    // wave-uniform row pointer, and only the first k-quad of a unit (the one that contains j = i + 1) needs a mask.
     const int units = 2 * (F - 1);
+    const int F4 = (F + 3) & ~3, nq = F4 >> 2;                  // k-quads per dw; 2 * nq <= C0T_MAXKS
+    float avA[C0T_MAXKS];
+    int woff[C0T_MAXKS];
+    {
+        const int x = x0 + r;
+#pragma unroll
+        for (int ks = 0; ks < C0T_MAXKS; ++ks) {
+            const int dwk = ks >= nq ? 1 : 0, j = 4 * (ks - dwk * nq) + kk;
+            const bool valid = ks < 2 * nq && j < F;
+            const float ev = Es[(valid ? j : 0) * Dp + 2 * x + dwk];
+            avA[ks] = valid ? ev : 0.f;
+            woff[ks] = valid ? (dwk * PpT + j) * PpT + q0 + r : q0 + r;
+        }
+    }
     for (int u = wave; u < units; u += NW) {
         const int i = u % (F - 1), dh = u / (F - 1);
-        const int nj = F - 1 - i, K = 2 * nj;                   // k = dw * nj + (j - i - 1)
-        const int base = i * (2 * F - i - 1) / 2;
-        const int x = x0 + r;
-        float bw[C0T_MAXKS], av[C0T_MAXKS];
+        const int base = i * (2 * F - i - 1) / 2;               // first pair (i, i+1); pair (i, j) is row base + j - i - 1
+        const int s0 = (i + 1) >> 2;                            // first k-quad with a j > i
+        const float* wb = a.W + ((int64_t)(dh * 2) * PpT + base - i - 1) * PpT;     // + woff = row of (dw, j), column q
+        float bw[C0T_MAXKS];
 #pragma unroll
-        for (int ks = 0; ks < C0T_MAXKS; ++ks) {                // every fragment of the unit is requested up front:
-            const int k = 4 * ks + kk;                          // 16 independent L2 loads and 16 independent LDS reads
-            const bool ok = k < K;
-            const int dw = (ok && k >= nj) ? 1 : 0, jj = ok ? k - dw * nj : 0;
-            bw[ks] = (dbg & 2) ? 1.f : (ok ? a.W[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] : 0.f);
-            av[ks] = ok ? Es[(i + 1 + jj) * Dp + 2 * x + dw] : 0.f;
+        for (int ks = 0; ks < C0T_MAXKS; ++ks) {
+            const int dwk = ks >= nq ? 1 : 0, t = ks - dwk * nq;
+            bw[ks] = 0.f;
+            if (t >= s0 && ks < 2 * nq) {                       // wave-uniform
+                if (t == s0) {                                  // the quad that holds j = i + 1: lanes with j <= i are masked
+                    const int j = 4 * t + kk;                   // (their address is moved onto the row of j = i + 1)
+                    const float wv = wb[woff[ks] + (j > i ? 0 : (i + 1 - j) * PpT)];
+                    bw[ks] = (j > i && !(dbg & 2)) ? wv : ((dbg & 2) ? 1.f : 0.f);
+                } else {
+                    bw[ks] = (dbg & 2) ? 1.f : wb[woff[ks]];
+                }
+            }
         }
-        // (measured at F32 D64: unconditional chains of 16/8 or 16/12/8/4 MFMAs ran this kernel 8 % and 20 % SLOWER than
-        // the test per k-step below - the forward has one unit per wave and step, so the skipped MFMAs are what counts)
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!(dbg & 4))
 #pragma unroll
-        for (int ks = 0; ks < C0T_MAXKS; ++ks)
-            if (4 * ks < K) acc = mfma16(av[ks], bw[ks], acc);  // wave-uniform skip of the empty k-steps
+        for (int ks = 0; ks < C0T_MAXKS; ++ks) {
+            const int dwk = ks >= nq ? 1 : 0, t = ks - dwk * nq;
+            if (t >= s0 && ks < 2 * nq) acc = mfma16(avA[ks], bw[ks], acc);      // wave-uniform skip of the empty k-quads
+        }
         float* tp = T + (dh * F + i) * TP + r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) tp[(kk * 4 + j) * 16] = acc[j];
@@ -2875,7 +2900,8 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         }
         return rc;
     }
-    if (l == 0 && conv0_fact_tile_ok(g)) return launch_conv0_fact_tile_fwd(a, st);   // rank-1 input channels: factorised, channel-tiled
+    // rank-1 input channels: factorised, channel-tiled (its step 1 indexes k over ALL fields: 2 * ceil4(F) <= 64 k values)
+    if (l == 0 && conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS) return launch_conv0_fact_tile_fwd(a, st);
     pick_nt(g.Pp / 16, &nblk, &NT);
     const bool big = a.Mtot >= 128 * 256;
     if (l == 0) {
