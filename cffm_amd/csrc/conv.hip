@@ -527,14 +527,13 @@ struct WgradArgs {
     int nslab, nxy;      // wgrad_kernel: gradient slabs and output tiles per slab (1-D grid, see xcd_tile)
 };
 
-// RI row tiles per wavefront: the workgroup's output tile is (64*RI) x (16*NT).  RI = 2 halves the dC traffic per MFMA
-// (a B fragment read from LDS feeds two row tiles) - the layers >= 1 of the wide shapes run it; RI = 1 keeps 4*Pp/64 exact
-// for every Pp and is what GEN (direct layer 0) uses.
-template <int NT, bool GEN, int RI = 1>
+// Generic form (64 x 16*NT output tile per workgroup): the direct layer 0 (GEN, F >= 33) and column-tile counts other than
+// 6 / 8; the layers >= 1 of the wide shapes run wgrad2_kernel below.
+template <int NT, bool GEN>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int RI = 1;                                            // row tiles per wavefront
     constexpr int BI = 64 * RI, LDA = BI + 16, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16), KM = WG_KM;
     constexpr int NB = KM * BQ / 256, NA = KM * BI / 4 / 256;     // per-thread B' floats / A' float4s per step
-    static_assert(!GEN || RI == 1, "the generated layer-0 operand is built for one row tile per wavefront");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);                       // [KM][LDB]
     float* As = Bs + KM * LDB;                                        // [KM][LDA]      (!GEN)
@@ -2158,19 +2157,19 @@ static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
     return 0;
 }
 
-template <int NT, bool GEN, int RI = 1>
+template <int NT, bool GEN>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
-    constexpr int BI = 64 * RI, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
+    constexpr int BI = 64, BQ = NT * 16, LDB = BQ + ((NT & 1) ? 0 : 16);
     const int S2 = 1 << (2 * a.lgSo);
     const int n_ex = GEN ? (WG_KM > S2 ? WG_KM / S2 : 1) : 0;
     const size_t lds = (size_t)(WG_KM * LDB + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : WG_KM * (BI + 16)) + 4) * 4;
-    int rc = set_lds(wgrad_kernel<NT, GEN, RI>, lds);
+    int rc = set_lds(wgrad_kernel<NT, GEN>, lds);
     if (rc) return rc;
     WgradArgs b = a;
     b.nslab = CFFM_NSLAB;                                                       // Pp > 64: conv_slabs() == CFFM_NSLAB
     b.nxy = ((4 * a.Pp + BI - 1) / BI) * a.qblocks;
     dim3 grid((unsigned)(8 * xcd_per(b.nslab) * b.nxy));
-    hipLaunchKernelGGL((wgrad_kernel<NT, GEN, RI>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((wgrad_kernel<NT, GEN>), grid, dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
