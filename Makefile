@@ -20,7 +20,8 @@ all: $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so $(PYEXT)
 
 # thin pybind11 layer over the C ABI (north_star: "through a thin pybind11 C-ABI layer"); links the library next to it
 $(PYEXT): cffm_amd/csrc_host/pybind_module.cpp include/cffm_hip.h $(OUT)/libcffm_hip.so
-	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden $(shell python3 -m pybind11 --includes) $< -o $@ -L$(OUT) -lcffm_hip -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden $(shell python3 -m pybind11 --includes) $< -o $@ -L$(OUT) -lcffm_hip -Wl,-rpath,'$$ORIGIN' \
+	  || echo 'WARNING: the pybind11 layer did not build (pybind11 / Python headers missing?); cffm_amd.hip.fast() falls back to ctypes'
 
 # host-only fast libfm reader
 $(OUT)/libcffm_libfm.so: cffm_amd/csrc_host/libfm_reader.cpp
