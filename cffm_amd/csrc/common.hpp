@@ -12,16 +12,29 @@
 // fused forward launch (slots 0-7), and of the sub-phases of its head phase (slots 8-15)
 static __device__ unsigned long long cffm_phase_times[16];
 static __device__ unsigned long long cffm_wg_times[2 * 1024];
+static __device__ unsigned long long cffm_bwd_times[48];     // backward launches: workgroup `wg` of a role, see tools/phase.py
+#define PHASE_MARKB(i, wg) do { if ((wg) == 7 && threadIdx.x == 0) cffm_bwd_times[i] = wall_clock64(); } while (0)
 #define PHASE_MARK(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[i] = wall_clock64(); } while (0)
 #define PHASE_MARK2(i) do {} while (0)
-#define PHASE_MARK3(i) do { if (CL != nullptr && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
+#define PHASE_MARK3(i) do { if (CL && blockIdx.x == 7 && threadIdx.x == 0) cffm_phase_times[8 + (i)] = wall_clock64(); } while (0)
 #else
 #define PHASE_MARK(i) do {} while (0)
 #define PHASE_MARK2(i) do {} while (0)
 #define PHASE_MARK3(i) do {} while (0)
+#define PHASE_MARKB(i, wg) do {} while (0)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// LDS byte offset of the copy of C_l that the fused forward keeps for its own later phases: C_0 at c0, C_1, C_2, ... packed
+// from c1 on ([S_l*S_l][Pp] floats each, S_l = D >> (l+1)).  Computed, not looked up: an array of offsets indexed by the
+// runtime layer number lives in scratch memory (a global-memory round trip per phase).
+__device__ __forceinline__ int fused_c_off(int l, int c0, int c1, int D, int Pp) {
+    if (l == 0) return c0;
+    int o = c1;
+    for (int k = 1; k < l; ++k) { const int S = D >> (k + 1); o += S * S * Pp * 4; }
+    return o;
+}
+
 
 #define CFFM_CHECK_LAUNCH()                          \
     do {                                             \
@@ -91,11 +104,34 @@ static inline int bwd_top_first_layer(const cffm_shape_t* s) {
     const int live = ilog2_i(s->D) - 1;
     return live - 2 >= 1 ? live - 2 : 1;
 }
-static inline int conv_slabs(const cffm_shape_t* s, int32_t B, int l) {
+// Slabs of a conv layer below the fused top: 256 when the layer has at least 64 rows per slab that way, else CFFM_NSLAB
+static inline int conv_slabs_plain(const cffm_shape_t* s, int32_t B, int l) {
     const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
     const int64_t S = s->D >> (l + 1);
-    if (bwd_top_ok(s, B) && l >= bwd_top_first_layer(s)) return 256;
     return (Pp <= 64 && (int64_t)B * S * S >= 256 * 64) ? 256 : CFFM_NSLAB;
+}
+// The layer right below the fused top runs its input and weight gradient as two roles of one launch
+// (conv_bwd_pair_kernel) when its slabs are shorter than 128 rows.
+static inline bool conv_pair_ok(const cffm_shape_t* s, int32_t B, int l) {
+    const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
+    const int64_t S = s->D >> (l + 1), rows = (int64_t)B * S * S;
+    const int nslab = conv_slabs_plain(s, B, l);
+    return l >= 1 && Pp <= 64 && (rows + nslab - 1) / nslab < 128;
+}
+// The weight gradients of the fused top's conv layers have few rows (B*4 and B*16 at D = 32): with one slab per example
+// they cost 2 x 256 slabs of 4*Pp*Pp floats (19 MB written and read again at frappe) for 5120 rows of work.  When a pair
+// launch follows the fused top, they run there instead, as two more roles over 64-row slabs (16 + 64 slabs at frappe).
+static inline bool top_wgrad_deferred(const cffm_shape_t* s, int32_t B) {
+    return bwd_top_ok(s, B) && conv_pair_ok(s, B, bwd_top_first_layer(s) - 1);
+}
+static inline int conv_slabs(const cffm_shape_t* s, int32_t B, int l) {
+    const int64_t S = s->D >> (l + 1);
+    if (bwd_top_ok(s, B) && l >= bwd_top_first_layer(s)) {
+        if (!top_wgrad_deferred(s, B)) return 256;
+        const int64_t n = ((int64_t)B * S * S + 63) / 64;
+        return n < 1 ? 1 : (n > 256 ? 256 : (int)n);
+    }
+    return conv_slabs_plain(s, B, l);
 }
 
 static inline void make_slab_plan(const cffm_shape_t* s, int32_t B, const cffm_theta_layout_t& tl, SlabPlan* p) {

@@ -843,6 +843,9 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgradArgs a) {
 extern "C" int cffm_debug_wg_times(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cffm_wg_times), sizeof(cffm_wg_times));
 }
+extern "C" int cffm_debug_bwd_times(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(cffm_bwd_times), sizeof(cffm_bwd_times));
+}
 extern "C" int cffm_debug_phase_times(unsigned long long* host16) {
     return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(cffm_phase_times), sizeof(cffm_phase_times));
 }
@@ -1125,7 +1128,8 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a) {
 //   step 2, wave w owns x = w, w+4, ...: rows y, k = (dh, i), B fragment = T[(dh,i)][x][q] (row pitch padded by
 //                             16 floats so the two k rows of a half-wave hit disjoint banks).
 template <int NT, int NW = 4>
-__device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem, float* outL = nullptr) {
+// staged (fused forward): the caller has put the filter and the embedding tile into LDS and passed the barrier
+__device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, char* smem, float* outL = nullptr, bool staged = false) {
     constexpr int PP = NT * 16, NTH = 64 * NW, XQ = 16 / NW;      // NW wavefronts; step 2 gives each XQ columns at a time
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16;
     const int TP = S * PP + 16;                                 // pitch of one (dh, i) plane of T
@@ -1133,7 +1137,7 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
     float* T = Wl + 4 * PP * PP;                                // [2F][TP]
     float* Es = T + 2 * F * TP;                                 // [F][Dp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
-    {   // stage the filter and the embedding tile (one barrier)
+    if (!staged) {   // stage the filter and the embedding tile (one barrier)
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
         for (int i = tid; i < 4 * PP * PP / 4; i += NTH) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
         const float* e = a.in + (int64_t)b * F * D;
@@ -1142,8 +1146,8 @@ __device__ __forceinline__ void conv0_fact_fwd_body(const ConvArgs& a, int b, ch
             const int f = fast_div(i, invD), d = i - f * D;
             Es[f * Dp + d] = e[i];
         }
+        lds_barrier();
     }
-    lds_barrier();
     // ---- step 1: unit (dh, i, rt) with all NT column tiles at once (one A fragment feeds NT MFMAs) ---------------
     const int units = 2 * (F - 1) * RT;
     for (int u = wave; u < units; u += NW) {
@@ -1244,7 +1248,10 @@ struct FwdAllArgs {
     unsigned long long* keys_sorted;
     int live, n_rows, id_bits, B;
     int rank_keys;                // 0: the keys are placed later, by the inner-branch role of bwd_top_kernel
-    int c_off[CFFM_MAX_LAYERS];   // byte offsets of the LDS copies of C_l inside the dynamic LDS, -1: activations go through global
+    int c0_off, c1_off;           // LDS byte offsets of the copy of C_0 and of the packed copies of C_1.. (fused_c_off); c0_off < 0:
+                                  // the activations go through global memory
+    int early_off, es_off;        // early_off > 0: LDS byte offset of the inner branch's scratch (= the T planes of layer 0), es_off: of
+                                  // the embedding tile of layer 0 - the layer-0 operands are then staged during the gather
 };
 
 
@@ -1266,10 +1273,23 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
     int c[RANK_MAXF];
 #pragma unroll
     for (int f = 0; f < RANK_MAXF; ++f) c[f] = 0;
-    for (int j = tid; j < n; j += 64 * NW) {
-        const unsigned long long kj = ((unsigned long long)(unsigned)ids[j] << 32) | (unsigned)j;
+    // n <= 4096 candidates: this thread's ids are fetched in groups of 8 independent loads (one L2 latency per group
+    // instead of one per candidate: 10 in a row at the frappe shape)
+    constexpr int GRP = 8;
+    for (int j0 = tid; j0 < n; j0 += 64 * NW * GRP) {
+        unsigned idj[GRP];
 #pragma unroll
-        for (int f = 0; f < RANK_MAXF; ++f) c[f] += kj < mine[f] ? 1 : 0;
+        for (int u = 0; u < GRP; ++u) {
+            const int j = j0 + 64 * NW * u;
+            idj[u] = (unsigned)ids[j < n ? j : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int j = j0 + 64 * NW * u;
+            const unsigned long long kj = j < n ? (((unsigned long long)idj[u] << 32) | (unsigned)j) : ~0ull;   // ~0: below no key
+#pragma unroll
+            for (int f = 0; f < RANK_MAXF; ++f) c[f] += kj < mine[f] ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int f = 0; f < RANK_MAXF; ++f) {
@@ -1292,27 +1312,59 @@ __device__ __forceinline__ void rank_keys_body(const int32_t* __restrict__ ids, 
 // two wavefronts to switch between, which is what hides the LDS / MFMA / L2 latencies of the per-example phases.
 // ACT >= 0: the activation id compiled in (selu / elu / relu of the three README commands): the act switches of the inner
 // branch, of the A operands of the conv layers and of the pooling sweep fold into straight code
+// The layer-0 filter on its way to LDS: fetch() issues this thread's float4 loads (before the gather's), operator() - called by
+// inner_fwd_body while the gathered rows are in flight - stores them at their LDS place.  Held by value, static indices only.
+template <int N, int NTH>
+struct ParkFilter {
+    float4 w[N];
+    float4* dst;
+    int n4;
+    __device__ __forceinline__ void fetch(const float4* src, float4* dst_, int n4_) {
+        dst = dst_; n4 = src != nullptr ? n4_ : 0;
+#pragma unroll
+        for (int ii = 0; ii < N; ++ii) {
+            const int i = threadIdx.x + NTH * ii;
+            w[ii] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void operator()() const {
+#pragma unroll
+        for (int ii = 0; ii < N; ++ii) {
+            const int i = threadIdx.x + NTH * ii;
+            if (i < n4) dst[i] = w[ii];
+        }
+    }
+};
+
 template <int NT, int NW, int ACT = -1>
 __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
     constexpr int G = NW / 4, PP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS copies of the conv outputs of this example (fa.c_off[l] >= 0): layer l+1 and the head read them there, the
     // global copies (needed by the backward) are written behind the LDS-only barriers and drain in the background
-    float* CL[CFFM_MAX_LAYERS];
-#pragma unroll
-    for (int l = 0; l < CFFM_MAX_LAYERS; ++l) CL[l] = fa.c_off[l] >= 0 ? reinterpret_cast<float*>(smem + fa.c_off[l]) : nullptr;
-    const bool lds_act = fa.c_off[0] >= 0;
+    auto CL = [&](int l) -> float* {
+        return fa.c0_off >= 0 ? reinterpret_cast<float*>(smem + fused_c_off(l, fa.c0_off, fa.c1_off, fa.inner.g.D, PP)) : nullptr;
+    };
+    const bool lds_act = fa.c0_off >= 0;
 #ifdef CFFM_PHASE_TIMERS
     if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x] = wall_clock64();
 #endif
     for (int b = blockIdx.x; b < fa.B; b += gridDim.x) {
         if (b != (int)blockIdx.x) __syncthreads();
-        if (fa.rank_keys) rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem);
+        // early (fa.early_off > 0): the layer-0 filter is fetched first of all, the inner branch works in the LDS that the T
+        // planes of layer 0 take later, so that W_0 reaches its LDS place while the gather is in flight, and the gather leaves
+        // the outer rows in the embedding tile: layer 0 then starts on LDS-resident operands
+        ParkFilter<(4 * PP * PP / 4 + 64 * NW - 1) / (64 * NW), 64 * NW> park;
+        const bool early = fa.early_off > 0;
+        park.fetch(early ? reinterpret_cast<const float4*>(fa.conv[0].W) : nullptr, reinterpret_cast<float4*>(smem), 4 * PP * PP / 4);
+        char* smem_i = smem + fa.early_off;
+        if (fa.rank_keys) rank_keys_body<NW>(fa.ids, fa.n_rows, b, fa.inner.g.F, fa.keys_sorted, smem_i);
         PHASE_MARK(0);
-        inner_fwd_body<ACT>(fa.inner, b, smem);            // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
+        // gathers Ei/Eo/fb of example b (full barrier inside), inner_out[b]
+        inner_fwd_body<ACT>(fa.inner, b, smem_i, early ? reinterpret_cast<float*>(smem + fa.es_off) : nullptr, fa.inner.g.D + 1, park);
         if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1);
-        conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem, CL[0]);   // reads Eo[b], writes C_0[b]
+        conv0_fact_fwd_body<NT, NW>(fa.conv[0], b, smem, CL(0), early);   // reads Eo[b], writes C_0[b]
         for (int l = 1; l < fa.live; ++l) {
             if (lds_act) lds_barrier(); else __syncthreads();
             PHASE_MARK(1 + l);
@@ -1321,17 +1373,17 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
             if (rows >= 64) {
                 for (int64_t m0 = m_lo; m0 < m_hi; m0 += 64) {
                     if (m0 > m_lo) lds_barrier();
-                    conv_fwd_taps_body<NT, 4 / G, false, G, ACT>(ca, m0, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                    conv_fwd_taps_body<NT, 4 / G, false, G, ACT>(ca, m0, m_hi, smem, CL(l - 1), CL(l), m_lo);
                 }
             } else if (rows >= 32) {
-                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G, ACT>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                conv_fwd_taps_body<NT, (G >= 2 ? 1 : 2), false, G, ACT>(ca, m_lo, m_hi, smem, CL(l - 1), CL(l), m_lo);
             } else {
-                conv_fwd_taps_body<NT, 1, false, G, ACT>(ca, m_lo, m_hi, smem, CL[l - 1], CL[l], m_lo);
+                conv_fwd_taps_body<NT, 1, false, G, ACT>(ca, m_lo, m_hi, smem, CL(l - 1), CL(l), m_lo);
             }
         }
         if (lds_act) lds_barrier(); else __syncthreads();
         PHASE_MARK(1 + fa.live);
-        head_fwd_body<NW, ACT>(fa.head, b, smem, lds_act ? CL : nullptr);
+        head_fwd_body<NW, ACT>(fa.head, b, smem, lds_act, fa.c0_off, fa.c1_off);
         PHASE_MARK(2 + fa.live);
     }
 #ifdef CFFM_PHASE_TIMERS
@@ -1369,6 +1421,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     float* sw = slabW + (int64_t)blockIdx.x * slab_stride;
     float* sb = slabB + (int64_t)blockIdx.x * slab_stride;
+    PHASE_MARKB(12, blockIdx.x);
     {
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
         for (int i = tid; i < 4 * PP * PP / 4; i += NTH) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
@@ -1395,6 +1448,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
         }
         __syncthreads();
         const float* dCb = a.dC + (int64_t)b * S * S * PP;
+        PHASE_MARKB(13, blockIdx.x);
         // ---- A: T ----------------------------------------------------------------------------------------------
         for (int u = wave; u < 2 * (F - 1); u += NW) {
             const int i = u % (F - 1), dh = u / (F - 1);
@@ -1422,6 +1476,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             T[(dh * F + F - 1) * TP + o] = 0.f;
         }
         __syncthreads();
+        PHASE_MARKB(14, blockIdx.x);
         // ---- B: dEi = dC (rows y) x T^T, this wave's k = its four x -----------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1465,6 +1520,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             dEi[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();                                          // T fully consumed: phase C may overwrite it
+        PHASE_MARKB(15, blockIdx.x);
         // ---- C: dT = E^T (rows (dh,i)) x dC, this wave's columns = its four x; db from the B fragments ------------
         {
             float av[2][4];                                      // A[m = rt*16 + r][k = y = 4s + kk]
@@ -1508,6 +1564,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             }
         }
         __syncthreads();
+        PHASE_MARKB(16, blockIdx.x);
         // ---- D: dW slab rows (dh, dw, (i, j>i)) ---------------------------------------------------------------------
         {
             int ucount = 0;
@@ -1543,10 +1600,15 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
                     }
                 }
         }
+        PHASE_MARKB(17, blockIdx.x);
         // ---- E: dEj = dT (rows x) x W^T over this wave's (dh, i) units -------------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-            for (int u = wave; u < 2 * (F - 1); u += NW) {
+            // no barrier separates D from E: E's units are dealt starting at the first wavefront that had one D unit less
+            // (20 D units and 18 E units on 16 wavefronts at frappe: 3 units on the slowest wavefront instead of 4)
+            int ud = 0;
+            for (int i = 0; i < F - 1; ++i) ud += 2 * ((2 * (F - 1 - i) + 15) / 16);
+            for (int u = (wave + NW - ud % NW) % NW; u < 2 * (F - 1); u += NW) {
                 const int i = u % (F - 1), dh = u / (F - 1), base = i * (2 * F - i - 1) / 2;
                 const float* ta = T + (dh * F + i) * TP + r * PP + 4 * kk;
                 const float* wrow[2];
@@ -1575,6 +1637,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[(wave * 16 + kk * 4 + j) * 32 + ct * 16 + r] = acc[ct][j];
         }
+        PHASE_MARKB(18, blockIdx.x);
         if (tid < 2 * F) {                                       // row sums and <ds0, E[f]> for the closed-form s0 terms
             const int f = tid % F;
             float sacc = 0.f;
@@ -1590,6 +1653,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             dEj[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();
+        PHASE_MARKB(19, blockIdx.x);
         // ---- F -----------------------------------------------------------------------------------------------------
         for (int e = tid; e < F * D; e += NTH) {
             const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
@@ -1601,6 +1665,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
         }
         first = false;
     }
+    PHASE_MARKB(20, blockIdx.x);
     // ---- bias gradient and empty-slab zeros -----------------------------------------------------------------------------
     __syncthreads();
 #pragma unroll
@@ -1620,6 +1685,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
     if (first) {                                                  // no example for this slab
         for (int e = tid; e < 4 * PP * PP; e += NTH) sw[e] = 0.f;
     }
+    PHASE_MARKB(25, blockIdx.x);
 }
 
 // HALVES = 2 (layer 0 only): 8 wavefronts, the upper four take the second half of the workgroup's m tiles, so
@@ -1903,7 +1969,62 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, in
         for (int i = 0; i < NT; ++i) { const uint32_t ij = lut[i * 16 + r]; fi[i] = (ij & 0xffff) * Dp; fj[i] = (ij >> 16) * Dp; }
     }
 
-    for (int64_t ms = m_lo; ms < m_hi; ms += WGT_SUB) {       // sub-chunks of the slab's rows
+    // One example of a small layer (<= 64 rows, the fused README launches): every A' load of the wave is issued before
+    // dC is staged, so the two memory latencies overlap and no k-step waits for a load of its own (the generic loop
+    // below pays one global-load latency per group of UNR k-steps: 4 in a row at 64 rows).
+    bool done_small = false;
+    if constexpr (!GEN && HALVES == 1 && NT <= 4) {
+        if (m_hi - m_lo <= 16 * UNR) {
+            done_small = true;
+            const int dbgw = (a.lgSo == 3 && m_lo_o < 0) ? slab : -1;
+            PHASE_MARKB(32, dbgw);
+            const int nrow = (int)max((int64_t)0, m_hi - m_lo), nk = (nrow + 3) / 4;
+            float av[4][UNR][NT];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g * UNR < nk) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        int64_t m = m_lo + 4 * (g * UNR + u) + kk;
+                        if (g * UNR + u >= nk || m >= a.Mtot) m = a.Mtot - 1;      // B' is zero there, any finite A' will do
+                        const RowPos rp = row_pos(m, a.lgSo);
+                        const float* arow = a.in + (((int64_t)rp.b * Sin + 2 * rp.y + dh) * Sin + 2 * rp.x + dw) * PP + r;
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) av[g][u][i] = arow[16 * i];
+                    }
+                }
+            __syncthreads();                                   // the caller's previous use of this LDS is over
+            {
+                const float4* src = reinterpret_cast<const float4*>(a.dC + m_lo * PP);
+                for (int e = tid; e < nrow * (PP / 4); e += NTH) reinterpret_cast<float4*>(Bs)[e] = src[e];
+                for (int e = nrow * (PP / 4) + tid; e < 4 * nk * (PP / 4); e += NTH)
+                    reinterpret_cast<float4*>(Bs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();
+            PHASE_MARKB(33, dbgw);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g * UNR < nk) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+                        if (g * UNR + u < nk) {
+                            float bv[NT];
+#pragma unroll
+                            for (int q = 0; q < NT; ++q) bv[q] = Bs[(4 * (g * UNR + u) + kk) * PP + q * 16 + r];
+#pragma unroll
+                            for (int q = 0; q < NT; ++q) bs[q] += bv[q];
+#pragma unroll
+                            for (int i = 0; i < NT; ++i) {
+                                const float x = act_pos(av[g][u][i], act);
+#pragma unroll
+                                for (int q = 0; q < NT; ++q) acc[i][q] = mfma16(x, bv[q], acc[i][q]);
+                            }
+                        }
+                }
+        }
+    }
+    PHASE_MARKB(34, (a.lgSo == 3 && m_lo_o < 0 && done_small) ? slab : -1);
+    for (int64_t ms = m_lo; ms < m_hi && !done_small; ms += WGT_SUB) {       // sub-chunks of the slab's rows
         const int nrow = (int)min((int64_t)WGT_SUB, m_hi - ms);
         const int b_lo = (int)(ms >> (2 * a.lgSo));
         __syncthreads();                                       // previous sub-chunk fully consumed
@@ -2031,13 +2152,48 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
 // one launch, one cold-cache ramp and one drain less per layer.  The top layer's launch can also carry the backward
 // of the inner branch (n_i workgroups, first in dispatch order: the longest role), which depends on dL/dout only
 // and would otherwise sit on a mostly idle chip while the small top layers run.
+// tw (top_wgrad_deferred): the weight gradients of the fused top's conv layers, over 64-row slabs - few workgroups, dispatched
+// right after the inner role.
+struct TopWgrad { WgradArgs w[2]; int n[2]; };
 template <int NT, int RM, int ACT = -1>
-__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i) {
+__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i,
+                                                            TopWgrad tw, int xcd_align) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) cffm_wg_times[2 * blockIdx.x] = wall_clock64();
+#endif
+    // dispatch order = longest first: the inner branch, the layer's weight gradient (one workgroup per CU at 256 slabs), the
+    // deferred top-layer weight gradients, then the many short input-gradient workgroups, which fill the gaps
     if (bid < n_i) inner_bwd_body<ACT>(ib, bid, n_i, smem);
-    else if (bid < n_i + n_d) dgrad_taps_body<NT, RM, false, 1, ACT>(d, bid - n_i, smem);
-    else wgrad_taps_body<NT, false, 1, ACT>(w, bid - n_i - n_d, n_w, smem);
+    else if ((bid -= n_i) < n_w) {
+        PHASE_MARKB(23, bid);
+        wgrad_taps_body<NT, false, 1, ACT>(w, bid, n_w, smem);
+        PHASE_MARKB(24, bid);
+    } else if ((bid -= n_w) < tw.n[0]) {
+        PHASE_MARKB(30, bid);
+        wgrad_taps_body<NT, false, 1, ACT>(tw.w[0], bid, tw.n[0], smem);
+        PHASE_MARKB(31, bid);
+    } else if ((bid -= tw.n[0]) < tw.n[1]) wgrad_taps_body<NT, false, 1, ACT>(tw.w[1], bid, tw.n[1], smem);
+    else {
+        // Both the weight- and the input-gradient role read C_{l-1} of their example (A' operand / mask).  Workgroups are
+        // dealt to the 8 XCDs round-robin and the weight-gradient workgroup of example e sits on XCD e % 8 when xcd_align is
+        // set (the host checks that both roles start at a block index that is a multiple of 8): the input-gradient
+        // workgroups of e are mapped to the same XCD, so that its L2 fetches the rows once for both.
+        bid -= tw.n[1];
+        int wg = bid;
+        const int wpe = (1 << (2 * d.lgSo)) / (16 * RM);             // workgroups per example
+        if (xcd_align && wpe >= 1) {
+            const int x = bid & 7, q = bid >> 3;
+            wg = (8 * (q / wpe) + x) * wpe + q % wpe;
+        }
+        PHASE_MARKB(21, bid);
+        dgrad_taps_body<NT, RM, false, 1, ACT>(d, wg, smem);
+        PHASE_MARKB(22, bid);
+    }
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // Top of the backward in ONE launch (B <= 256, Pp <= 64): workgroup b runs, for example b, the head backward and then
@@ -2050,6 +2206,7 @@ struct BwdTopArgs {
     WgradArgs w[2];
     int lgSo[2];
     int n_layers;                 // 1 or 2 conv layers (top first)
+    int wgrad_here;               // 0: the weight gradients of these layers run in the pair launch that follows (top_wgrad_deferred)
     InnerBwdArgs ib;
     int n_inner;                  // workgroups of the inner-branch role (0: none)
     const int32_t* rank_ids;      // non-NULL: the inner-branch role also places the sparse-update keys of its examples
@@ -2065,27 +2222,38 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
     __shared__ float red[4];
     const int bid = blockIdx.x;
     if (bid < a.n_inner) {                                   // ---- role 1: inner branch
+        PHASE_MARKB(36, bid);
         const float L = head_bwd_loss(a.hb, false, red);
         __syncthreads();
+        PHASE_MARKB(37, bid);
         if (a.rank_ids != nullptr) {
             for (int b = bid; b < a.hb.B; b += a.n_inner) rank_keys_body<4>(a.rank_ids, a.n_rows, b, a.hb.g.F, a.keys_sorted, smem);
         }
+        PHASE_MARKB(38, bid);
         inner_bwd_body<ACT>(a.ib, bid, a.n_inner, smem, L);
+        PHASE_MARKB(39, bid);
         return;
     }
     const int b = bid - a.n_inner;                           // ---- role 2: example b (also slab b of every range)
+    PHASE_MARKB(0, b);
     HeadBwdState st;
     head_bwd_begin(a.hb, b, st);
+    PHASE_MARKB(1, b);
     const float L = head_bwd_loss(a.hb, b == 0, red);
+    PHASE_MARKB(2, b);
     if (b < a.hb.B)
         head_bwd_example<ACT>(a.hb, b, st, b, head_dout(a.hb.loss, a.hb.out[b], a.hb.y[b], 1.f / (float)a.hb.Bg, L), dh1s, dt1s);
+    PHASE_MARKB(3, b);
     head_bwd_end(a.hb, b, st);
+    PHASE_MARKB(4, b);
     for (int t = 0; t < a.n_layers; ++t) {
         __syncthreads();                                     // dC of this layer (global, written above) is complete
         const int64_t rows = 1ll << (2 * a.lgSo[t]);
         const int64_t m_lo = (int64_t)b * rows, m_hi = b < a.hb.B ? m_lo + rows : m_lo;
-        wgrad_taps_body<NT, false, 1, ACT>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
+        if (a.wgrad_here) wgrad_taps_body<NT, false, 1, ACT>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
+        PHASE_MARKB(5 + 2 * t, b);
         for (int64_t m0 = m_lo; m0 < m_hi; m0 += 16) dgrad_taps_body<NT, 1, false, 1, ACT>(a.d[t], 0, smem, m0, m_hi);
+        PHASE_MARKB(6 + 2 * t, b);
     }
 }
 
@@ -2826,20 +2994,31 @@ static int launch_wgrad_taps(const WgradArgs& a, int nsl, hipStream_t st) {
 }
 
 template <int NT, int RM>
-static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl, const InnerBwdArgs* ib, int n_i, hipStream_t st) {
+static int launch_conv_bwd_pair(const DgradArgs& d, const WgradArgs& w, int nsl, const InnerBwdArgs* ib, int n_i, hipStream_t st,
+                                const TopWgrad* twp = nullptr) {
     constexpr int BM = 16 * RM;
+    TopWgrad tw;
+    memset(&tw, 0, sizeof(tw));
+    if (twp) tw = *twp;
     const int n_d = (int)((d.Mtot + BM - 1) / BM);
-    size_t lds = (size_t)(WGT_SUB * NT * 16) * 4 + 16;
+    // a slab of a paired layer has fewer than 128 rows (conv_pair_ok): half of WGT_SUB, so that four workgroups share a CU
+    size_t lds = (size_t)(128 * NT * 16) * 4 + 16;
     InnerBwdArgs none;
     memset(&none, 0, sizeof(none));
     if (ib && inner_bwd_lds(ib->g) > lds) lds = inner_bwd_lds(ib->g);
+    // XCD alignment of the two roles (see the kernel): one weight-gradient slab per example, whole groups of 8 examples, and
+    // both roles starting at a block index that is a multiple of 8
+    const int S2 = 1 << (2 * d.lgSo);
+    const int first_w = ib ? n_i : 0, first_d = first_w + nsl + tw.n[0] + tw.n[1];
+    const int xcd_align = (nsl == d.B && (int64_t)nsl * S2 == d.Mtot && S2 % BM == 0 && d.B % 8 == 0 && first_w % 8 == 0 &&
+                           first_d % 8 == 0) ? 1 : 0;
     // activation compiled in for the README commands (see launch_fwd_all)
 #define PAIR_GO(ACT_)                                                                                                          \
     do {                                                                                                                        \
         int rc_ = set_lds(conv_bwd_pair_kernel<NT, RM, ACT_>, lds);                                                             \
         if (rc_) return rc_;                                                                                                    \
-        hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM, ACT_>), dim3(n_d + nsl + (ib ? n_i : 0)), dim3(256), lds, st, d, w, n_d, \
-                           nsl, ib ? *ib : none, ib ? n_i : 0);                                                                 \
+        hipLaunchKernelGGL((conv_bwd_pair_kernel<NT, RM, ACT_>), dim3(n_d + nsl + (ib ? n_i : 0) + tw.n[0] + tw.n[1]), dim3(256), \
+                           lds, st, d, w, n_d, nsl, ib ? *ib : none, ib ? n_i : 0, tw, xcd_align);                              \
     } while (0)
     if (NT == 3 && d.act == CFFM_ACT_SELU) PAIR_GO(CFFM_ACT_SELU);
     else if (NT == 1 && d.act == CFFM_ACT_ELU) PAIR_GO(CFFM_ACT_ELU);
@@ -2970,6 +3149,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
     memset(&a, 0, sizeof(a));
     fill_head_bwd_args(s, theta, ws, y, B, B_global, local_sum, loss_out, unscaled, &a.hb);
     const int first = bwd_top_first_layer(s);
+    a.wgrad_here = top_wgrad_deferred(s, B) ? 0 : 1;
     a.n_layers = 0;
     for (int l = g.live - 1; l >= first; --l) {
         fill_taps_bwd_args(s, theta, ws, B, l, &a.d[a.n_layers], &a.w[a.n_layers]);
@@ -2996,7 +3176,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
 // which: bit 0 = weight/bias gradient, bit 1 = input gradient (the two only share their inputs, so the fused
 // step runs them on different streams)
 static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st, int which = 3,
-                        bool* with_inner = nullptr) {
+                        bool* with_inner = nullptr, bool with_top_wgrad = false) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -3046,8 +3226,19 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             int n_i = 0;
             const bool inner = with_inner != nullptr && s->inner_conv;
             if (inner) n_i = fill_inner_bwd_args(s, theta, ws, B, &ib);
-            if (wg16 >= 2 * 512) { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 2>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st))); }
-            else { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 1>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st))); }
+            TopWgrad tw;
+            memset(&tw, 0, sizeof(tw));
+            if (with_top_wgrad) {                               // the fused top left its weight gradients to this launch
+                int k = 0;
+                for (int lt = g.live - 1; lt > l && k < 2; --lt, ++k) {
+                    DgradArgs unused;
+                    fill_taps_bwd_args(s, theta, ws, B, lt, &unused, &tw.w[k]);
+                    tw.n[k] = sp.r[sp.conv0 + lt].nslab;
+                }
+            }
+            const TopWgrad* twp = with_top_wgrad ? &tw : nullptr;
+            if (wg16 >= 2 * 512) { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 2>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st, twp))); }
+            else { DISPATCH_NT4(g.Pp / 16, rc = (launch_conv_bwd_pair<NT_, 1>(da, wa, sr.nslab, inner ? &ib : nullptr, n_i, st, twp))); }
             if (inner && !rc) *with_inner = true;
             return rc;
         }
@@ -3144,6 +3335,11 @@ extern "C" int cffm_outer_conv0_bwd(const cffm_shape_t* s, const float* theta, v
     if (B <= 0 || !s->outer_conv) return 0;
     return conv_bwd_any(s, theta, ws, B, 0, (hipStream_t)stream);
 }
+// the layer right below the fused top, carrying the top layers' weight gradients (top_wgrad_deferred)
+int cffm_conv_bwd_below_top(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st) {
+    return conv_bwd_any(s, theta, ws, B, layer, st, 3, nullptr, true);
+}
+
 extern "C" int cffm_conv_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
@@ -3241,13 +3437,19 @@ int cffm_fwd_all_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const flo
         low = (low + 255) / 256 * 256;
         size_t base0 = lds > low + small ? lds : low + small;
         base0 = (base0 + 255) / 256 * 256;
-        for (int l = 0; l < CFFM_MAX_LAYERS; ++l) fa.c_off[l] = -1;
+        fa.c0_off = -1; fa.c1_off = 0;
         if (base0 + c0 <= 160 * 1024 - 512) {
-            fa.c_off[0] = (int)base0;
-            size_t o = low;
-            for (int l = 1; l < g.live; ++l) { fa.c_off[l] = (int)o; o += (size_t)(g.D >> (l + 1)) * (g.D >> (l + 1)) * PP * 4; }
+            fa.c0_off = (int)base0;
+            fa.c1_off = (int)low;
             lds = base0 + c0;
         }
+    }
+    {   // the inner branch (and the key placement) must fit into the T planes, below the embedding tile
+        const size_t t_off = (size_t)4 * PP * PP * 4, t_bytes = (size_t)2 * g.F * (S * PP + 16) * 4;
+        size_t need = inner_fwd_lds(g);
+        if (need < (size_t)8 * RANK_MAXF * 4) need = (size_t)8 * RANK_MAXF * 4;
+        fa.early_off = (need <= t_bytes && ids != nullptr) ? (int)t_off : 0;
+        fa.es_off = (int)(t_off + t_bytes);
     }
     int rc = 0;
     DISPATCH_NT4(PP / 16, rc = (launch_fwd_all<NT_>(fa, lds, st)));

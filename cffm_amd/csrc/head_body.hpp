@@ -36,9 +36,10 @@ static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFF
 
 // NW wavefronts: the pooling sweeps, the embedding tile and s0 use all of them; the dense(32) partials stay on the
 // first 256 threads (8 parts x 32 units)
-// CL != nullptr (fused forward): LDS copies of this example's conv outputs, read instead of the global ones
+// CL (fused forward): LDS copies of this example's conv outputs (at fused_c_off(l, c0_off, c1_off, ..) inside smem) are read
+// instead of the global ones
 template <int NW = 4, int ACTC = -1>
-__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem, float* const* CL = nullptr) {
+__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem, bool CL = false, int c0_off = 0, int c1_off = 0) {
     const int act = ACTC >= 0 ? ACTC : a.g.act;         // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int NTH = 64 * NW, RPW = 16 / NW;                    // rows per wave in one pooling sweep
     float* t1s = reinterpret_cast<float*>(smem);                   // [1024]
@@ -119,7 +120,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
             const int S = g.D >> (l + 1);
             const int n4 = S * g.Pp / 4;
-            const float4* base = CL ? reinterpret_cast<const float4*>(CL[l])
+            const float4* base = CL ? reinterpret_cast<const float4*>(smem + fused_c_off(l, c0_off, c1_off, g.D, g.Pp))
                                     : reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);
             // wave w owns rows w, w+4, ...; four rows are swept together so that four loads are in flight per lane
             for (int y0 = wave; y0 < S; y0 += 16) {

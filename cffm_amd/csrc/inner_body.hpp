@@ -46,8 +46,14 @@ struct InnerFwdArgs {
 static inline size_t inner_fwd_lds(const Geo& g) { return (size_t)(g.F * g.K + g.Pp + 16) * 4; }   // + up to 16 wavefront partials
 
 // ACTC >= 0: the activation id as a compile-time constant (the README shapes): every act switch folds away
-template <int ACTC = -1>
-__device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, char* smem) {
+// EoL != nullptr (fused forward): the gather also leaves the outer rows of the example in LDS, [F][EoLp] floats, where the
+// factorised layer 0 reads them - that phase then starts without a trip to global memory.
+// mid(): called once by every thread between the first batch of gather loads and their use - the fused forward parks the
+// layer-0 filter in LDS there (its loads were issued before the gather's and return first).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int ACTC = -1, class Mid = NoMid>
+__device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, char* smem, float* EoL = nullptr, int EoLp = 0,
+                                               Mid mid = Mid()) {
     const Geo& g = ia.g;
     const int act = ACTC >= 0 ? ACTC : g.act;
     const float* Ei = ia.Ei; const float* cw_g = ia.cw; const float* cb_g = ia.cb; const float* wd = ia.wd;
@@ -59,17 +65,35 @@ __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, ch
     if (fg.ids != nullptr) {
         const int K4 = g.K / 4, D4 = fg.D / 4;
         const int32_t* idb = fg.ids + (int64_t)b * g.F;
-        for (int i = threadIdx.x; i < g.F * (K4 + D4); i += blockDim.x) {
+        const int n_piece = g.F * (K4 + D4);
+        float4 v_first = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x < n_piece) {                  // the first piece of every thread is in flight across mid()
+            const int i = threadIdx.x;
             const bool in = i < g.F * K4;
             const int j = in ? i : i - g.F * K4, per = in ? K4 : D4, f = j / per, c = j - f * per;
             int id = idb[f];
             id = id < 0 ? 0 : (id >= fg.M ? fg.M - 1 : id);
-            const float4 v = reinterpret_cast<const float4*>(in ? fg.inner : fg.outer)[(int64_t)id * per + c];
+            v_first = reinterpret_cast<const float4*>(in ? fg.inner : fg.outer)[(int64_t)id * per + c];
+        }
+        mid();
+        for (int i = threadIdx.x; i < n_piece; i += blockDim.x) {
+            const bool in = i < g.F * K4;
+            const int j = in ? i : i - g.F * K4, per = in ? K4 : D4, f = j / per, c = j - f * per;
+            float4 v = v_first;
+            if (i != (int)threadIdx.x) {
+                int id = idb[f];
+                id = id < 0 ? 0 : (id >= fg.M ? fg.M - 1 : id);
+                v = reinterpret_cast<const float4*>(in ? fg.inner : fg.outer)[(int64_t)id * per + c];
+            }
             if (in) {
                 reinterpret_cast<float4*>(E)[j] = v;
                 reinterpret_cast<float4*>(fg.Ei + (int64_t)b * g.F * g.K)[j] = v;
             } else {
                 reinterpret_cast<float4*>(fg.Eo + (int64_t)b * g.F * fg.D)[j] = v;
+                if (EoL != nullptr) {
+                    float* e = EoL + f * EoLp + 4 * c;
+                    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+                }
             }
         }
         if (threadIdx.x < g.F) {
@@ -80,20 +104,25 @@ __device__ __forceinline__ void inner_fwd_body(const InnerFwdArgs& ia, int b, ch
             fg.keys[slot] = ((unsigned long long)(unsigned)((raw < 0 || raw >= fg.M) ? fg.M : raw) << 32) | (unsigned long long)slot;   // bad id -> key M
         }
     } else {
+        mid();
         const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * g.F * g.K);
         for (int i = threadIdx.x; i < FK4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
     }
     build_pair_lut(lut, g.F, g.Pp);
     float cw[4] = {cw_g[0], cw_g[1], cw_g[2], cw_g[3]};
     float cb[2] = {cb_g[0], cb_g[1]};
-    __syncthreads();
     const int K2 = g.K / 2, units = g.P * K2;
+    // dense(1) weights of unit u = p*K2 + t: flat index p*K + t*2 + ch (:333) = 2u + ch; the first pair of every thread is
+    // fetched before the barrier, behind the gather
+    const float2* wd2 = reinterpret_cast<const float2*>(wd);
+    const float2 w2_first = (int)threadIdx.x < units ? wd2[threadIdx.x] : make_float2(0.f, 0.f);
+    __syncthreads();
     const float invK2 = 1.f / (float)K2;
     float part = 0.f;
     for (int u = threadIdx.x; u < units; u += blockDim.x) {
         const int p = fast_div(u, invK2), t = u - p * K2;
         const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, act);
-        const float2 w2 = *reinterpret_cast<const float2*>(&wd[(int64_t)p * g.K + 2 * t]);   // flat index p*K + t*2 + ch (:333)
+        const float2 w2 = u == (int)threadIdx.x ? w2_first : wd2[u];
         part += v.s0 * w2.x + v.s1 * w2.y;
     }
     const float tot = block_sum(part, red);
@@ -142,20 +171,30 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
     const int K2 = g.K / 2, units = g.P * K2;
     const float invK2 = 1.f / (float)K2;
     float gcw[4] = {0.f, 0.f, 0.f, 0.f}, gcb[2] = {0.f, 0.f}, gdb = 0.f;
+    // dense(1) weights of unit u = p*K2 + t sit at flat index p*K + 2t = 2u (:333) and do not depend on the example: the
+    // first UPRE units of every thread are fetched once, before any barrier
+    constexpr int UPRE = 4;
+    const float2* wd2 = reinterpret_cast<const float2*>(wd);
+    float2 w2p[UPRE];
+#pragma unroll
+    for (int k = 0; k < UPRE; ++k) {
+        const int u = threadIdx.x + k * blockDim.x;
+        w2p[k] = u < units ? wd2[u] : make_float2(0.f, 0.f);
+    }
     bool first = true;
     for (int b = slab; b < B; b += nslab) {
+        // dL/dout of the example: its loads are in flight together with the embedding rows
+        const float db = dout ? dout[b] : head_dout(a.loss, a.out[b], a.y[b], a.invB, L);
         __syncthreads();
         const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * FK);
         for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
         for (int i = threadIdx.x; i < 4 * FK; i += blockDim.x) dE[i] = 0.f;
         __syncthreads();
-        const float db = dout ? dout[b] : head_dout(a.loss, a.out[b], a.y[b], a.invB, L);
         float* myE = dE + wave * FK;
-        for (int u = threadIdx.x; u < units; u += blockDim.x) {
+        auto unit_step = [&](int u, float2 w2) {
             const int p = fast_div(u, invK2), t = u - p * K2;
             const InnerUnit v = inner_unit(E, lut, p, t, g.K, cw, cb, act);
             const int64_t wi = (int64_t)p * g.K + 2 * t;
-            const float2 w2 = *reinterpret_cast<const float2*>(&wd[wi]);
             // dense(1) kernel gradient: flat * dout
             float2 acc2 = first ? make_float2(0.f, 0.f) : *reinterpret_cast<float2*>(&slab_dw[wi]);
             acc2.x += v.s0 * db; acc2.y += v.s1 * db;
@@ -174,7 +213,13 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
             atomicAdd(&myE[v.i * g.K + 2 * t + 1], dI1 * v.ejy);
             atomicAdd(&myE[v.j * g.K + 2 * t], dI0 * v.eix);
             atomicAdd(&myE[v.j * g.K + 2 * t + 1], dI1 * v.eiy);
+        };
+#pragma unroll
+        for (int k = 0; k < UPRE; ++k) {
+            const int u = threadIdx.x + k * blockDim.x;
+            if (u < units) unit_step(u, w2p[k]);
         }
+        for (int u = threadIdx.x + UPRE * blockDim.x; u < units; u += blockDim.x) unit_step(u, wd2[u]);
         if (threadIdx.x == 0) gdb += db;
         __syncthreads();
         for (int i = threadIdx.x; i < FK; i += blockDim.x)
@@ -184,12 +229,25 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
     if (first) {   // this slab saw no example: it must still read as zeros
         for (int64_t i = threadIdx.x; i < (int64_t)g.P * g.K; i += blockDim.x) slab_dw[i] = 0.f;
     }
-    float r[7];
-    for (int q = 0; q < 4; ++q) r[q] = block_sum(gcw[q], red);
-    r[4] = block_sum(gcb[0], red);
-    r[5] = block_sum(gcb[1], red);
-    r[6] = block_sum(gdb, red);
+    // the seven scalar gradients in ONE block reduction (wavefront partials through the idle dE planes, added in
+    // wavefront order): two barriers instead of fourteen
+    float r[7] = {gcw[0], gcw[1], gcw[2], gcw[3], gcb[0], gcb[1], gdb};
+#pragma unroll
+    for (int q = 0; q < 7; ++q) r[q] = wave_sum(r[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) dE[wave * 8 + q] = r[q];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            float t = 0.f;
+            for (int w = 0; w < nw; ++w) t += dE[w * 8 + q];
+            r[q] = t;
+        }
         for (int q = 0; q < 4; ++q) slab_cw[q] = r[q];
         slab_cb[0] = r[4]; slab_cb[1] = r[5];
         slab_db[0] = r[6];

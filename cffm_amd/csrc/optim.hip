@@ -311,9 +311,21 @@ __global__ __launch_bounds__(256) void sparse_adagrad_kernel(SparseArgs a) { spa
 __global__ __launch_bounds__(256) void update_all_kernel(const float* __restrict__ gpart, int64_t n, SlabPlan sp,
                                                          float* __restrict__ grad, float* __restrict__ theta,
                                                          float* __restrict__ acc, float lr, int n_reduce, SparseArgs sa) {
-    if ((int)blockIdx.x < n_reduce) reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, theta, acc, lr);
-    else sparse_adagrad_body(blockIdx.x - n_reduce, sa);
+    if ((int)blockIdx.x < n_reduce) {
+        PHASE_MARKB(26, blockIdx.x);
+        reduce_slabs_body(blockIdx.x, gpart, n, sp, grad, theta, acc, lr);
+        PHASE_MARKB(27, blockIdx.x);
+    } else {
+        PHASE_MARKB(28, blockIdx.x - n_reduce);
+        sparse_adagrad_body(blockIdx.x - n_reduce, sa);
+        PHASE_MARKB(29, blockIdx.x - n_reduce);
+    }
 }
+#ifdef CFFM_PHASE_TIMERS
+extern "C" int cffm_debug_upd_times(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(cffm_bwd_times), sizeof(cffm_bwd_times));
+}
+#endif
 
 extern "C" int cffm_reduce_slabs(const cffm_shape_t* s, void* ws, int32_t B, float* grad, void* stream) {
     return cffm_reduce_slabs_impl(s, ws, B, grad, nullptr, nullptr, 0.f, (hipStream_t)stream);

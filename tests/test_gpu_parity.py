@@ -460,6 +460,27 @@ def test_second_step_and_reproducibility():
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=None if k not in slack else slack[k].reshape(v.shape))
 
 
+@pytest.mark.parametrize('name', ['f33-d32-relu', 'f16-d32-b130', 'f20-d64-elu', 'frappe-b1024-dups', 'frappe-selu'])
+def test_two_runs_bit_identical(name):
+    """Every kernel family leaves the same bits on two runs of the same two steps: the direct layer-0 kernels (F >= 33,
+    whose LDS float atomics only ever target the issuing wave's PRIVATE accumulator plane, so their order is the
+    program order of one wave), the tiled layer-0 kernels (F = 16 / 20), the fused small-shape launches (frappe) and
+    the sorted sparse update under heavy id duplication."""
+    cfg, p32, X, y = make_case(name)
+    X2 = np.ascontiguousarray(X[::-1])
+    outs = []
+    for _ in range(2):
+        eng = engine_for(cfg, p32)
+        l1 = eng.train_step(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())
+        l2 = eng.train_step(torch.from_numpy(X2).cuda(), torch.from_numpy(y).cuda())
+        torch.cuda.synchronize()
+        outs.append((eng.export_params(), eng.export_accumulators(), float(l1), float(l2)))
+    assert outs[0][2:] == outs[1][2:]
+    for which in (0, 1):
+        for k, v in outs[0][which].items():
+            np.testing.assert_array_equal(v, outs[1][which][k], err_msg=k)
+
+
 @pytest.mark.parametrize('loss', ['mse', 'mae', 'log_loss', 'hybrid'])
 def test_other_losses(loss):
     CASES['tmp-' + loss] = dict(M=80, F=4, K=8, D=8, act='elu', B=12, loss=loss)
