@@ -2155,8 +2155,10 @@ __global__ __launch_bounds__(256 * HALVES) void wgrad_taps_kernel(WgradArgs a) {
 // tw (top_wgrad_deferred): the weight gradients of the fused top's conv layers, over 64-row slabs - few workgroups, dispatched
 // right after the inner role.
 struct TopWgrad { WgradArgs w[2]; int n[2]; };
+// 4 wavefronts per SIMD up to Pp = 48 (110 VGPRs, nothing spilled): 1024 resident workgroups.  Without the bound the kernel took
+// 96 + 36 accumulation registers = 3 per SIMD, and the last 80 of the 848 workgroups of the frappe launch started 9 us late.
 template <int NT, int RM, int ACT = -1>
-__global__ __launch_bounds__(256) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i,
+__global__ __launch_bounds__(256, (NT <= 3 ? 4 : 1)) void conv_bwd_pair_kernel(DgradArgs d, WgradArgs w, int n_d, int n_w, InnerBwdArgs ib, int n_i,
                                                             TopWgrad tw, int xcd_align) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bid = blockIdx.x;

@@ -16,7 +16,7 @@ buf = (C.c_ulonglong * 2048)()
 lib = hip.load()
 lib.cffm_debug_wg_times.argtypes = [C.c_void_p]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 848
-roles = [('top L3', 0, 16), ('top L2', 16, 80), ('dgrad', 80, 592), ('wgrad L1', 592, 848)] if n == 848 else [('dgrad', 0, 512), ('wgrad', 512, 768)]
+roles = [('wgrad L1', 0, 256), ('top L3', 256, 272), ('top L2', 272, 336), ('dgrad', 336, 848)] if n == 848 else [('wgrad', 0, 256), ('dgrad', 256, 768)]
 for i in range(3):
     eng.train_step(X[i % 8], y[i % 8]); torch.cuda.synchronize()
     lib.cffm_debug_wg_times(buf)
@@ -27,3 +27,8 @@ for i in range(3):
     for name, lo, hi in roles:
         ss, ee = s[lo:hi], e[lo:hi]
         print('  %-9s start p50 %5d max %5d | dur p50 %5d max %5d | end p50 %5d max %5d' % (name, np.median(ss), ss.max(), np.median(ee - ss), (ee - ss).max(), np.median(ee), ee.max()))
+    late = np.nonzero(s > 2000)[0]
+    print('  workgroups starting later than 2 us: %d' % late.size, 'first/last index', (late.min(), late.max()) if late.size else None,
+          'start p50 %d' % (np.median(s[late]) if late.size else 0))
+    first_end = np.sort(e)[:8]
+    print('  earliest ends:', first_end)
