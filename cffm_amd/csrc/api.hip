@@ -168,12 +168,16 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
                                     rank_ids)))
             return rc;
         inner_done = true;
+        if (bwd_fused01_ok(s, B)) {            // layers 3..0 below the fused top: one launch
+            if ((rc = cffm_conv01_bwd_impl(s, theta, ws, B, stream))) return rc;
+            next = 0;
+        }
         for (int l = next; l >= 1; --l) {
             if (l == next && top_wgrad_deferred(s, B)) rc = cffm_conv_bwd_below_top(s, theta, ws, B, l, stream);
             else rc = cffm_conv_bwd(s, theta, ws, B, l, stream);
             if (rc) return rc;
         }
-        if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
+        if (!bwd_fused01_ok(s, B) && (rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
     } else {
         if ((rc = cffm_head_bwd_impl(s, theta, ws, y, B, B_global, fused || loss_out != nullptr, loss_out, stream, unscaled))) return rc;
         if (s->outer_conv) {

@@ -121,11 +121,24 @@ static inline bool conv_pair_ok(const cffm_shape_t* s, int32_t B, int l) {
 // The weight gradients of the fused top's conv layers have few rows (B*4 and B*16 at D = 32): with one slab per example
 // they cost 2 x 256 slabs of 4*Pp*Pp floats (19 MB written and read again at frappe) for 5120 rows of work.  When a pair
 // launch follows the fused top, they run there instead, as two more roles over 64-row slabs (16 + 64 slabs at frappe).
+// D = 32 (four conv layers) with Pp <= 48 and 64 <= B <= 256, i.e. the frappe command: everything below the fused top - the
+// weight gradients of layers 3, 2, 1, the input gradient of layer 1 and the factorised backward of layer 0 - runs in ONE
+// launch with one 16-wavefront workgroup per example (conv01_bwd_kernel); every conv layer then has one slab per example.
+#define CFFM_TOP_SLAB_ROWS 32      // rows per slab of layers 2 and 3 in conv01_bwd_kernel (half of what the layer-1 group of a workgroup handles)
+static inline bool bwd_fused01_ok(const cffm_shape_t* s, int32_t B) {
+    const int F = s->F, Pp = (F * (F - 1) / 2 + 15) / 16 * 16;
+    return bwd_top_ok(s, B) && s->D == 32 && Pp <= 48 && B >= 64;
+}
 static inline bool top_wgrad_deferred(const cffm_shape_t* s, int32_t B) {
-    return bwd_top_ok(s, B) && conv_pair_ok(s, B, bwd_top_first_layer(s) - 1);
+    return bwd_top_ok(s, B) && !bwd_fused01_ok(s, B) && conv_pair_ok(s, B, bwd_top_first_layer(s) - 1);
 }
 static inline int conv_slabs(const cffm_shape_t* s, int32_t B, int l) {
     const int64_t S = s->D >> (l + 1);
+    if (bwd_fused01_ok(s, B)) {                  // layers 0, 1: one slab per example; layers 2, 3: slabs of CFFM_TOP_SLAB_ROWS rows
+        if (l <= 1) return 256;
+        const int64_t n = ((int64_t)B * S * S + CFFM_TOP_SLAB_ROWS - 1) / CFFM_TOP_SLAB_ROWS;
+        return n < 1 ? 1 : (int)n;
+    }
     if (bwd_top_ok(s, B) && l >= bwd_top_first_layer(s)) {
         if (!top_wgrad_deferred(s, B)) return 256;
         const int64_t n = ((int64_t)B * S * S + 63) / 64;

@@ -1402,11 +1402,11 @@ __global__ __launch_bounds__(64 * NW) void fwd_all_kernel(FwdAllArgs fa) {
 //   E  dEj[(dw,j)][x]   = sum_{dh,i<j,q} dT[dh][i][x][q] * W[dh][dw][(i,j)][q]   rows x, k = q, cols (dw,j)
 //   F  dEo[f][h] = dEi[(h&1,f)][h>>1] + dEj[(h&1,f)][h>>1] + ds0[h]*R_f + Q_f  (s0 pool gradient in closed form)
 // ~1640 MFMAs per example against 4608 for the direct wgrad + dgrad, no atomics, fixed summation order.
+// wg / nwg: this workgroup's slab and the number of slabs (= workgroups of the launch)
 template <int NT, int F_, int D_, int NW>
-__global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, float* __restrict__ slabW,
-                                                              float* __restrict__ slabB, int64_t slab_stride) {
-    constexpr int PP = NT * 16, S = 16, NTH = 64 * NW, XQ = 16 / NW;     // NW wavefronts (4 or 8), XQ x columns per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void conv0_fact_bwd_body(const DgradArgs& a, float* __restrict__ slabW, float* __restrict__ slabB,
+                                                    int64_t slab_stride, char* smem, int wg, int nwg) {
+    constexpr int PP = NT * 16, S = 16, NTH = 64 * NW, XQ = 16 / NW;     // NW wavefronts (4, 8 or 16), XQ x columns per wave
     // F_/D_ != 0: the README shapes compiled in, so that the pair indexing, the divisions and the loop bounds fold
     const int F = F_ ? F_ : a.F, D = D_ ? D_ : a.D, Dp = D + 1, P = F_ ? F_ * (F_ - 1) / 2 : a.P, F2 = 2 * F;
     const int TP = S * PP + 16;
@@ -1419,9 +1419,9 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
     float* rs = bred + NW * PP;                                  // [F] row sums, [F] dots
     float* Es = rs + 2 * F;                                     // [F][Dp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
-    float* sw = slabW + (int64_t)blockIdx.x * slab_stride;
-    float* sb = slabB + (int64_t)blockIdx.x * slab_stride;
-    PHASE_MARKB(12, blockIdx.x);
+    float* sw = slabW + (int64_t)wg * slab_stride;
+    float* sb = slabB + (int64_t)wg * slab_stride;
+    PHASE_MARKB(12, wg);
     {
         const float4* wsrc = reinterpret_cast<const float4*>(a.W);
         for (int i = tid; i < 4 * PP * PP / 4; i += NTH) reinterpret_cast<float4*>(Wl)[i] = wsrc[i];
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bacc[nt] = 0.f;
 
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int b = wg; b < a.B; b += nwg) {
         __syncthreads();
         {
             const float* e = a.Cprev + (int64_t)b * F * D;      // Eo rows of this example
@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
         }
         __syncthreads();
         const float* dCb = a.dC + (int64_t)b * S * S * PP;
-        PHASE_MARKB(13, blockIdx.x);
+        PHASE_MARKB(13, wg);
         // ---- A: T ----------------------------------------------------------------------------------------------
         for (int u = wave; u < 2 * (F - 1); u += NW) {
             const int i = u % (F - 1), dh = u / (F - 1);
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             T[(dh * F + F - 1) * TP + o] = 0.f;
         }
         __syncthreads();
-        PHASE_MARKB(14, blockIdx.x);
+        PHASE_MARKB(14, wg);
         // ---- B: dEi = dC (rows y) x T^T, this wave's k = its four x -----------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             dEi[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();                                          // T fully consumed: phase C may overwrite it
-        PHASE_MARKB(15, blockIdx.x);
+        PHASE_MARKB(15, wg);
         // ---- C: dT = E^T (rows (dh,i)) x dC, this wave's columns = its four x; db from the B fragments ------------
         {
             float av[2][4];                                      // A[m = rt*16 + r][k = y = 4s + kk]
@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             }
         }
         __syncthreads();
-        PHASE_MARKB(16, blockIdx.x);
+        PHASE_MARKB(16, wg);
         // ---- D: dW slab rows (dh, dw, (i, j>i)) ---------------------------------------------------------------------
         {
             int ucount = 0;
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
                     }
                 }
         }
-        PHASE_MARKB(17, blockIdx.x);
+        PHASE_MARKB(17, wg);
         // ---- E: dEj = dT (rows x) x W^T over this wave's (dh, i) units -------------------------------------------------
         {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[(wave * 16 + kk * 4 + j) * 32 + ct * 16 + r] = acc[ct][j];
         }
-        PHASE_MARKB(18, blockIdx.x);
+        PHASE_MARKB(18, wg);
         if (tid < 2 * F) {                                       // row sums and <ds0, E[f]> for the closed-form s0 terms
             const int f = tid % F;
             float sacc = 0.f;
@@ -1653,7 +1653,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
             dEj[(e & 31) * 16 + (e >> 5)] = v;
         }
         __syncthreads();
-        PHASE_MARKB(19, blockIdx.x);
+        PHASE_MARKB(19, wg);
         // ---- F -----------------------------------------------------------------------------------------------------
         for (int e = tid; e < F * D; e += NTH) {
             const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
         }
         first = false;
     }
-    PHASE_MARKB(20, blockIdx.x);
+    PHASE_MARKB(20, wg);
     // ---- bias gradient and empty-slab zeros -----------------------------------------------------------------------------
     __syncthreads();
 #pragma unroll
@@ -1685,7 +1685,14 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
     if (first) {                                                  // no example for this slab
         for (int e = tid; e < 4 * PP * PP; e += NTH) sw[e] = 0.f;
     }
-    PHASE_MARKB(25, blockIdx.x);
+    PHASE_MARKB(25, wg);
+}
+
+template <int NT, int F_, int D_, int NW>
+__global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, float* __restrict__ slabW,
+                                                              float* __restrict__ slabB, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv0_fact_bwd_body<NT, F_, D_, NW>(a, slabW, slabB, slab_stride, smem, blockIdx.x, gridDim.x);
 }
 
 // HALVES = 2 (layer 0 only): 8 wavefronts, the upper four take the second half of the workgroup's m tiles, so
@@ -1700,14 +1707,17 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_bwd_kernel(DgradArgs a, fl
 // version spent 83 K LDS cycles per CU).
 // m_lo / m_end (fused top-of-backward kernel): the tiles start at m_lo and rows >= m_end are masked instead of a.Mtot
 template <int NT, int RM, bool L0, int HALVES, int ACTC = -1>
-__device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem, int64_t m_lo = 0, int64_t m_end = -1) {
+// tiles (layers >= 1): 16*RM-row tiles per workgroup; with HALVES groups of four tap-wavefronts each group takes its share
+// tid_in >= 0 (conv01_bwd_kernel): the body runs on a sub-range of a larger workgroup, tid_in = thread index inside it
+__device__ __forceinline__ void dgrad_taps_body(const DgradArgs& a, int wg, char* smem, int64_t m_lo = 0, int64_t m_end = -1,
+                                                int tiles = 1, int tid_in = -1) {
     const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, BM = 16 * RM, NTH = 256 * HALVES, NCOPY = 4 * HALVES;
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);        // L0 only: [PP]
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2, r = lane & 15, kk = lane >> 4;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
-    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
+    const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM * tiles;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
     const int mtiles = rows_per_wg / BM;
     const int64_t Mend = m_end < 0 ? a.Mtot : m_end;
@@ -1936,15 +1946,17 @@ __global__ __launch_bounds__(256 * HALVES) void dgrad_taps_kernel(DgradArgs a) {
 // loads from L2, or, for layer 0, generated from the embedding tiles held in LDS.  With HALVES = 2 the
 // sub-chunk is cut in two and the two partial blocks of a tap are added (lower half first) through LDS.
 #define WGT_SUB 256
+// tid_in >= 0 (conv01_bwd_kernel): the body runs on ONE group of 256 threads of a larger workgroup, tid_in = thread index inside it;
+// store = false: a group without a slab of its own only keeps the barriers
 template <int NT, bool GEN, int HALVES, int ACTC = -1>
 __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, int nslab, char* smem, int64_t m_lo_o = -1,
-                                                int64_t m_hi_o = -1) {
+                                                int64_t m_hi_o = -1, int tid_in = -1, bool store = true) {
     const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, UNR = 4, NTH = 256 * HALVES;
     float* Bs = reinterpret_cast<float*>(smem);               // [WGT_SUB][PP]
     uint32_t* lut = reinterpret_cast<uint32_t*>(Bs + WGT_SUB * PP);   // GEN: [PP]
     float* Es = reinterpret_cast<float*>(lut + (GEN ? PP : 0));       // GEN: [n_ex][F][Dp] of the sub-chunk's examples
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, tap = wid & 3, half = wid >> 2;
     const int r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, P = a.P, Dp = a.D + 1, S2 = So * So, dh = tap >> 1, dw = tap & 1;
     const int n_ex_max = GEN ? WGT_SUB / S2 + 2 : 0;
@@ -2123,6 +2135,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, in
         }
     }
     // ---- write this slab -----------------------------------------------------------------------------------
+    if (!store) return;
     float* sw = a.slabW + (int64_t)slab * a.slab_stride + (int64_t)tap * PP * PP;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -2196,6 +2209,58 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 4 : 1)) void conv_bwd_pair_kernel(D
 #ifdef CFFM_PHASE_TIMERS
     if (threadIdx.x == 0 && blockIdx.x < 1024) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
 #endif
+}
+
+// Everything below the fused top for one example per workgroup (bwd_fused01_ok: D = 32, Pp <= 48, the frappe command): with
+// 16 wavefronts = 4 groups of four tap-wavefronts,
+//   1. the input gradient of layer 1 -> dC_0 of the example (64 rows: one 16-row tile per group),
+//   2. the weight gradients of layers 1, 2, 3 side by side, one group each (64 / 16 / 4 rows: the small path of
+//      wgrad_taps_body, two barriers for every group), slab = example,
+//   3. the factorised backward of layer 0, which finds dC_0 in this CU's L2 slice instead of HBM.
+// One launch boundary and one operand burst less than conv_bwd_pair_kernel + conv0_fact_bwd_kernel, and the top-layer weight
+// gradients leave the critical chain of bwd_top_kernel.
+struct Conv01Args {
+    DgradArgs d0;                 // layer 0
+    float *slabW0, *slabB0;
+    int64_t stride0;
+    DgradArgs d1;                 // input gradient of layer 1
+    WgradArgs w1, w2, w3;         // weight gradients of layers 1, 2, 3
+    int n2, n3;                   // slabs of layers 2 and 3, CFFM_TOP_SLAB_ROWS rows each (workgroup b < n carries slab b of that layer)
+};
+
+template <int NT, int F_, int D_, int ACT>
+__global__ __launch_bounds__(1024) void conv01_bwd_kernel(Conv01Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // grp as a SCALAR (readfirstlane): whatever is selected by it below is selected per wavefront with scalar branches.  (A first
+    // version branched on the per-lane value around code with barriers: that is compiled to exec masking, under which a
+    // wavefront can run through the barriers of a branch it did not take - the launch hung.)
+    const int b = blockIdx.x, grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), ltid = threadIdx.x & 255;
+    PHASE_MARKB(40, b);
+    dgrad_taps_body<NT, 1, false, 4, ACT>(a.d1, b, smem, 0, -1, 4);
+    PHASE_MARKB(41, b);
+    {   // ONE call site for the four groups: its barriers sit in straight-line code that every wavefront runs.  Group 0:
+        // layer 1, slab = example b.  Groups 1 / 2: layers 2 / 3 over slabs of CFFM_TOP_SLAB_ROWS rows (2 / 8 examples each, their
+        // dC is complete since the fused top), carried by the first n2 / n3 workgroups only - one slab per example would cost
+        // 2 x 256 slabs of 4*Pp*Pp floats for 5,120 rows of work.  Group 3 only keeps the barriers.  Measured and not kept:
+        // the k-steps of layer 1 shared between groups 0 and 3 with an exchange through LDS (33.8 -> 34.9 us), and the input
+        // gradient on groups 2 / 3 at the same time as the weight gradients on groups 0 / 1 (34.6): these phases are bound by
+        // the L2-level traffic of the 256 workgroups (64 MB in 12 us), not by MFMA time or by a wavefront's latency chain.
+        char* gsm = smem + (size_t)grp * (64 * NT * 16 * 4);
+        const WgradArgs& w = grp == 0 ? a.w1 : (grp == 1 ? a.w2 : a.w3);
+        const int nsl = grp == 0 ? (int)gridDim.x : (grp == 1 ? a.n2 : a.n3);
+        const bool mine = grp < 3 && b < nsl;
+        int64_t m_lo = 0, m_hi = 0;
+        if (mine) {
+            const int64_t per = grp == 0 ? (1ll << (2 * w.lgSo)) : CFFM_TOP_SLAB_ROWS;
+            m_lo = (int64_t)b * per;
+            m_hi = min(w.Mtot, m_lo + per);
+            if (m_hi < m_lo) m_hi = m_lo;
+        }
+        wgrad_taps_body<NT, false, 1, ACT>(w, b, nsl, gsm, m_lo, m_hi, ltid, mine);
+    }
+    __syncthreads();                                         // the weight-gradient LDS is free, dC_0 is complete
+    PHASE_MARKB(42, b);
+    conv0_fact_bwd_body<NT, F_, D_, 16>(a.d0, a.slabW0, a.slabB0, a.stride0, smem, b, (int)gridDim.x);
 }
 
 // Top of the backward in ONE launch (B <= 256, Pp <= 64): workgroup b runs, for example b, the head backward and then
@@ -3151,7 +3216,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
     memset(&a, 0, sizeof(a));
     fill_head_bwd_args(s, theta, ws, y, B, B_global, local_sum, loss_out, unscaled, &a.hb);
     const int first = bwd_top_first_layer(s);
-    a.wgrad_here = top_wgrad_deferred(s, B) ? 0 : 1;
+    a.wgrad_here = (top_wgrad_deferred(s, B) || bwd_fused01_ok(s, B)) ? 0 : 1;   // 0: a later launch computes them
     a.n_layers = 0;
     for (int l = g.live - 1; l >= first; --l) {
         fill_taps_bwd_args(s, theta, ws, B, l, &a.d[a.n_layers], &a.w[a.n_layers]);
@@ -3340,6 +3405,55 @@ extern "C" int cffm_outer_conv0_bwd(const cffm_shape_t* s, const float* theta, v
 // the layer right below the fused top, carrying the top layers' weight gradients (top_wgrad_deferred)
 int cffm_conv_bwd_below_top(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st) {
     return conv_bwd_any(s, theta, ws, B, layer, st, 3, nullptr, true);
+}
+
+// bwd_fused01_ok: layers 3..0 below the fused top in one launch (conv01_bwd_kernel)
+int cffm_conv01_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, hipStream_t st) {
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    if (!bwd_fused01_ok(s, B) || g.live != 4 || !conv0_fact_bwd_ok(g)) return CFFM_ERR_UNSUPPORTED;
+    char* w = (char*)ws;
+    float* gpart = (float*)(w + wl.gpart);
+    SlabPlan sp;
+    make_slab_plan(s, B, tl, &sp);
+    Conv01Args a;
+    memset(&a, 0, sizeof(a));
+    const SlabRange& sr = sp.r[sp.conv0];
+    a.d0.dC = (const float*)(w + wl.dC[0]);
+    a.d0.W = theta + tl.conv_w[0];
+    a.d0.Cprev = (const float*)(w + wl.Eo);
+    a.d0.dt1 = (const float*)(w + wl.dt1);
+    a.d0.dprev = (float*)(w + wl.dEo);
+    a.d0.Mtot = layer_rows(g, B, 0, &a.d0.lgSo);
+    a.d0.B = B; a.d0.P = g.P; a.d0.Pp = g.Pp; a.d0.F = g.F; a.d0.D = g.D; a.d0.act = g.act;
+    a.d0.t1w = 2 * g.D - 2; a.d0.t1off = 0;
+    a.slabW0 = gpart + sr.base; a.slabB0 = a.slabW0 + (tl.conv_b[0] - tl.conv_w[0]); a.stride0 = sr.len;
+    DgradArgs unused;
+    fill_taps_bwd_args(s, theta, ws, B, 1, &a.d1, &a.w1);
+    fill_taps_bwd_args(s, theta, ws, B, 2, &unused, &a.w2);
+    fill_taps_bwd_args(s, theta, ws, B, 3, &unused, &a.w3);
+    a.n2 = sp.r[sp.conv0 + 2].nslab; a.n3 = sp.r[sp.conv0 + 3].nslab;
+    if (sp.r[sp.conv0].nslab != 256 || sp.r[sp.conv0 + 1].nslab != 256 || a.n2 > 256 || a.n3 > 256 ||
+        (int64_t)a.n2 * CFFM_TOP_SLAB_ROWS < a.w2.Mtot || (int64_t)a.n3 * CFFM_TOP_SLAB_ROWS < a.w3.Mtot)
+        return CFFM_ERR_UNSUPPORTED;             // one layer-0/1 slab per workgroup, the 64-row slabs cover layers 2 and 3
+    const int NW = 16, PP = g.Pp;
+    const size_t lds = (size_t)(4 * PP * PP + 2 * g.F * (16 * PP + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * PP + 2 * g.F +
+                                g.F * (g.D + 1)) * 4 + 16;                     // the layer-0 phases; the weight gradients need 3 x 64*PP*4
+#define CFFM_C01_LAUNCH(NTV, FV, DV, ACTV)                                                                       \
+    do {                                                                                                         \
+        int rc = set_lds(conv01_bwd_kernel<NTV, FV, DV, ACTV>, lds);                                             \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((conv01_bwd_kernel<NTV, FV, DV, ACTV>), dim3(256), dim3(1024), lds, st, a);          \
+    } while (0)
+    const int nt = PP / 16;
+    if (nt == 3 && g.F == 10 && g.act == CFFM_ACT_SELU) CFFM_C01_LAUNCH(3, 10, 32, CFFM_ACT_SELU);     // frappe (README.md:28)
+    else if (nt == 3) CFFM_C01_LAUNCH(3, 0, 0, -1);
+    else if (nt == 2) CFFM_C01_LAUNCH(2, 0, 0, -1);
+    else CFFM_C01_LAUNCH(1, 0, 0, -1);
+#undef CFFM_C01_LAUNCH
+    CFFM_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int cffm_conv_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, void* stream) {

@@ -33,6 +33,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
                       const int32_t* rank_ids = nullptr);
 // backward of conv layer `layer`; where the paired launch is available it also carries the inner-branch backward
 // (*inner_done = true), which the caller must then not launch again
+int cffm_conv01_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, hipStream_t st);
 int cffm_conv_bwd_below_top(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st);
 int cffm_conv_bwd_with_inner(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int32_t layer, hipStream_t st,
                              bool* inner_done);

@@ -50,3 +50,5 @@ print('conv0_fact_bwd (ns): W+E load %d, A %d, B %d, C %d, D %d, E %d, rs+sync+r
       % (d(12, 13), d(13, 14), d(14, 15), d(15, 16), d(16, 17), d(17, 18), d(18, 19), d(19, 20), d(20, 25), d(12, 25), d(21, 12)))
 print('update_all (ns): reduce role %d, sparse role %d; starts %d after conv0_fact_bwd start; step span bwd_top start -> update end %d'
       % (d(26, 27), d(28, 29), d(12, 26), max(d(0, 27), d(0, 29))))
+print('conv01_bwd (ns), when that launch replaces the pair launch + conv0_fact_bwd: input gradient of layer 1 %d, weight gradients of layers 1-3 %d, layer 0 %d | total %d; starts %d after bwd_top start'
+      % (d(40, 41), d(41, 42), d(42, 25), d(40, 25), d(0, 40)))
