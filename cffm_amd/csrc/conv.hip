@@ -2248,15 +2248,17 @@ __global__ __launch_bounds__(1024) void conv01_bwd_kernel(Conv01Args a) {
         char* gsm = smem + (size_t)grp * (64 * NT * 16 * 4);
         const WgradArgs& w = grp == 0 ? a.w1 : (grp == 1 ? a.w2 : a.w3);
         const int nsl = grp == 0 ? (int)gridDim.x : (grp == 1 ? a.n2 : a.n3);
-        const bool mine = grp < 3 && b < nsl;
+        // the slabs of layer 2 go to the LAST n2 workgroups, those of layer 3 to the first n3: no workgroup carries all three
+        const int slab = grp == 1 ? b - ((int)gridDim.x - a.n2) : b;
+        const bool mine = grp < 3 && slab >= 0 && slab < nsl;
         int64_t m_lo = 0, m_hi = 0;
         if (mine) {
             const int64_t per = grp == 0 ? (1ll << (2 * w.lgSo)) : CFFM_TOP_SLAB_ROWS;
-            m_lo = (int64_t)b * per;
+            m_lo = (int64_t)slab * per;
             m_hi = min(w.Mtot, m_lo + per);
             if (m_hi < m_lo) m_hi = m_lo;
         }
-        wgrad_taps_body<NT, false, 1, ACT>(w, b, nsl, gsm, m_lo, m_hi, ltid, mine);
+        wgrad_taps_body<NT, false, 1, ACT>(w, mine ? slab : 0, nsl, gsm, m_lo, m_hi, ltid, mine);
     }
     __syncthreads();                                         // the weight-gradient LDS is free, dC_0 is complete
     PHASE_MARKB(42, b);
