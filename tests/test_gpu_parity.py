@@ -94,6 +94,13 @@ CASES = {
     'no-inner-nolinatt': dict(M=700, F=10, K=32, D=32, act='relu', B=40, inner_conv=0, linear_att=0),
     'no-outer-nolinatt': dict(M=700, F=10, K=32, D=32, act='gelu', B=40, outer_conv=0, linear_att=0),
     'fm-only-nolinatt': dict(M=700, F=5, K=8, D=8, act='relu', B=300, inner_conv=0, outer_conv=0, linear_att=0),
+    # conv01_bwd_kernel (D = 32, Pp <= 48, 64 <= B <= 256) outside the frappe instance: the generic instances for Pp = 48 / 32 /
+    # 16, workgroups without an example (B < 256), a partial last slab of layers 2 / 3, the B = 64 edge and, one below it, the
+    # five-launch path of the same shape
+    'f10-d32-b100-elu': dict(M=900, F=10, K=16, D=32, act='elu', B=100),
+    'f7-d32-b64-gelu': dict(M=600, F=7, K=8, D=32, act='gelu', B=64),
+    'f5-d32-b200-relu': dict(M=400, F=5, K=32, D=32, act='relu', B=200),
+    'f7-d32-b63-gelu': dict(M=600, F=7, K=8, D=32, act='gelu', B=63),
 }
 HEAVY = [k for k, v in CASES.items() if v.get('heavy')]       # oracle needs several GB and ~a minute per pass
 LIGHT = [k for k in CASES if k not in HEAVY]
@@ -324,7 +331,7 @@ def test_backward_stages(name):
 TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
                'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
                'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
-               'fm-only-nolinatt']
+               'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu']
 
 
 @pytest.mark.parametrize('name,trained_like', [(n, t) for n in TRAIN_CASES for t in (True, False)] + [(n, True) for n in HEAVY])
