@@ -2244,7 +2244,9 @@ __global__ __launch_bounds__(1024) void conv01_bwd_kernel(Conv01Args a) {
         // 2 x 256 slabs of 4*Pp*Pp floats for 5,120 rows of work.  Group 3 only keeps the barriers.  Measured and not kept:
         // the k-steps of layer 1 shared between groups 0 and 3 with an exchange through LDS (33.8 -> 34.9 us), and the input
         // gradient on groups 2 / 3 at the same time as the weight gradients on groups 0 / 1 (34.6): these phases are bound by
-        // the L2-level traffic of the 256 workgroups (64 MB in 12 us), not by MFMA time or by a wavefront's latency chain.
+        // the L2-level traffic of the 256 workgroups (64 MB in 12 us), not by MFMA time or by a wavefront's latency chain.  Nor
+        // did cutting that traffic help: C_0 of the example staged ONCE in LDS (coalesced 16-byte loads issued first, parked behind
+        // the input gradient's own loads) for both the mask and the A' operand - 12.6 MB less - ran 32.9 -> 35.7 us.
         char* gsm = smem + (size_t)grp * (64 * NT * 16 * 4);
         const WgradArgs& w = grp == 0 ? a.w1 : (grp == 1 ? a.w2 : a.w3);
         const int nsl = grp == 0 ? (int)gridDim.x : (grp == 1 ? a.n2 : a.n3);
