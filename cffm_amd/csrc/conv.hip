@@ -2280,6 +2280,7 @@ struct BwdTopArgs {
     int wgrad_here;               // 0: the weight gradients of these layers run in the pair launch that follows (top_wgrad_deferred)
     InnerBwdArgs ib;
     int n_inner;                  // workgroups of the inner-branch role (0: none)
+    int n_keys;                   // > 0: the key placement runs in that many workgroups of its own (3 x 256 workgroups of 4 wavefronts fit the chip)
     const int32_t* rank_ids;      // non-NULL: the inner-branch role also places the sparse-update keys of its examples
     unsigned long long* keys_sorted;   // (moved here from the forward launch, where it sat on the critical path)
     int n_rows;
@@ -2292,20 +2293,33 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
     __shared__ float dt1s[1024];
     __shared__ float red[4];
     const int bid = blockIdx.x;
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x] = wall_clock64();
+#endif
     if (bid < a.n_inner) {                                   // ---- role 1: inner branch
         PHASE_MARKB(36, bid);
         const float L = head_bwd_loss(a.hb, false, red);
         __syncthreads();
         PHASE_MARKB(37, bid);
-        if (a.rank_ids != nullptr) {
+        if (a.rank_ids != nullptr && a.n_keys == 0) {
             for (int b = bid; b < a.hb.B; b += a.n_inner) rank_keys_body<4>(a.rank_ids, a.n_rows, b, a.hb.g.F, a.keys_sorted, smem);
         }
         PHASE_MARKB(38, bid);
         inner_bwd_body<ACT>(a.ib, bid, a.n_inner, smem, L);
         PHASE_MARKB(39, bid);
+#ifdef CFFM_PHASE_TIMERS
+        if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
         return;
     }
-    const int b = bid - a.n_inner;                           // ---- role 2: example b (also slab b of every range)
+    if (bid < a.n_inner + a.n_keys) {                        // ---- role 3 (n_keys > 0): the key placement as workgroups of its own
+        for (int b = bid - a.n_inner; b < a.hb.B; b += a.n_keys) rank_keys_body<4>(a.rank_ids, a.n_rows, b, a.hb.g.F, a.keys_sorted, smem);
+#ifdef CFFM_PHASE_TIMERS
+        if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
+        return;
+    }
+    const int b = bid - a.n_inner - a.n_keys;                // ---- role 2: example b (also slab b of every range)
     PHASE_MARKB(0, b);
     HeadBwdState st;
     head_bwd_begin(a.hb, b, st);
@@ -2321,11 +2335,14 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
         __syncthreads();                                     // dC of this layer (global, written above) is complete
         const int64_t rows = 1ll << (2 * a.lgSo[t]);
         const int64_t m_lo = (int64_t)b * rows, m_hi = b < a.hb.B ? m_lo + rows : m_lo;
-        if (a.wgrad_here) wgrad_taps_body<NT, false, 1, ACT>(a.w[t], b, (int)gridDim.x - a.n_inner, smem, m_lo, m_hi);
+        if (a.wgrad_here) wgrad_taps_body<NT, false, 1, ACT>(a.w[t], b, (int)gridDim.x - a.n_inner - a.n_keys, smem, m_lo, m_hi);
         PHASE_MARKB(5 + 2 * t, b);
         for (int64_t m0 = m_lo; m0 < m_hi; m0 += 16) dgrad_taps_body<NT, 1, false, 1, ACT>(a.d[t], 0, smem, m0, m_hi);
         PHASE_MARKB(6 + 2 * t, b);
     }
+#ifdef CFFM_PHASE_TIMERS
+    if (threadIdx.x == 0) cffm_wg_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -3200,7 +3217,7 @@ static int launch_bwd_top(const BwdTopArgs& a, size_t lds, hipStream_t st) {
     do {                                                                                                       \
         int rc_ = set_lds(bwd_top_kernel<NT, ACT_>, lds);                                                      \
         if (rc_) return rc_;                                                                                   \
-        hipLaunchKernelGGL((bwd_top_kernel<NT, ACT_>), dim3(a.n_inner + 256), dim3(256), lds, st, a);          \
+        hipLaunchKernelGGL((bwd_top_kernel<NT, ACT_>), dim3(a.n_inner + a.n_keys + 256), dim3(256), lds, st, a); \
     } while (0)
     if (NT == 3 && act == CFFM_ACT_SELU) TOP_GO(CFFM_ACT_SELU);
     else if (NT == 1 && act == CFFM_ACT_ELU) TOP_GO(CFFM_ACT_ELU);
@@ -3235,6 +3252,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
         cffm_ws_layout(s, B, &wl);
         a.rank_ids = rank_ids; a.n_rows = B * s->F;
         a.keys_sorted = (unsigned long long*)((char*)ws + wl.sort_vals);
+        a.n_keys = 256;
     }
     size_t lds = (size_t)(WGT_SUB * g.Pp) * 4 + 16;
     if (inner_bwd_lds(g) > lds) lds = inner_bwd_lds(g);

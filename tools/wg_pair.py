@@ -1,4 +1,5 @@
-"""Debug (make PHASE_TIMERS=1): start / end of every workgroup of conv_bwd_pair_kernel at the frappe shape, 100 MHz clock."""
+"""Debug (make PHASE_TIMERS=1): start / end of every workgroup of the last launch that records them - bwd_top_kernel at the frappe
+shape (512 workgroups: inner-branch role, example role), conv_bwd_pair_kernel at shapes that still use it."""
 import ctypes as C, sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
@@ -15,8 +16,9 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 2048)()
 lib = hip.load()
 lib.cffm_debug_wg_times.argtypes = [C.c_void_p]
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 848
-roles = [('wgrad L1', 0, 256), ('top L3', 256, 272), ('top L2', 272, 336), ('dgrad', 336, 848)] if n == 848 else [('wgrad', 0, 256), ('dgrad', 256, 768)]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+roles = {848: [('wgrad L1', 0, 256), ('top L3', 256, 272), ('top L2', 272, 336), ('dgrad', 336, 848)], 768: [('wgrad', 0, 256), ('dgrad', 256, 768)],
+         512: [('inner role', 0, 256), ('example role', 256, 512)]}[n]
 for i in range(3):
     eng.train_step(X[i % 8], y[i % 8]); torch.cuda.synchronize()
     lib.cffm_debug_wg_times(buf)
