@@ -567,7 +567,8 @@ def test_full_size_configs(name):
 
 
 @pytest.mark.parametrize('route,case', [('runs', 'bookx-relu'), ('rows', 'bookx-relu'), ('dense', 'bookx-relu'),
-                                        ('rows', 'no-inner'), ('runs', 'no-outer'), ('rows', 'fm-only-nolinatt')])
+                                        ('rows', 'no-inner'), ('runs', 'no-outer'), ('rows', 'fm-only-nolinatt'),
+                                        ('runs', 'frappe-selu'), ('dense', 'frappe-selu')])      # 2 x 128 examples: conv01_bwd_kernel
 def test_data_parallel_halves_on_one_gpu(route, case):
     """The N > 1 compute path without a second GPU: two 'ranks' (two engines holding the same replica) run the local half
     of the step on the two halves of a batch, the test plays the role of the two collectives (sum of the flat gradient
