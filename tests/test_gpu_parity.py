@@ -664,10 +664,11 @@ def test_merge_of_sorted_runs_equals_a_global_sort():
     assert not np.array_equal(a['outer_embeddings'], p32['outer_embeddings'])
 
 
-def test_regularised_square_loss_step():
+@pytest.mark.parametrize('case', ['bookx-relu', 'f10-d32-b100-elu'])     # the second: a conv01_bwd_kernel shape on the stage-by-stage path
+def test_regularised_square_loss_step(case):
     """--lamda > 0 (CFFM.py:489-491): l2_loss data term, dense table gradients scatter(row grads) + lamda * w with
     the outer table scaled by lamda_att (Q13), dense Adagrad over both tables, sparse feature_bias."""
-    cfg, p32, X, y = make_case('bookx-relu')
+    cfg, p32, X, y = make_case(case)
     cfg.lamda_bilinear = 0.02
     eng = engine_for(cfg, p32)
     p64 = to64(p32)
