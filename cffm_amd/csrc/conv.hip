@@ -3007,19 +3007,22 @@ static inline bool conv0_fact_ok(const Geo& g) {
     return lds <= 150 * 1024;
 }
 
+// LDS of conv0_fact_bwd_body with its 16 wavefronts: filter, T planes, partial tiles, dEi / dEj, bias partials, row sums,
+// embedding tile
+static inline size_t conv0_fact_bwd_lds(int Pp, int F, int D) {
+    const int NW = 16;
+    return (size_t)(4 * Pp * Pp + 2 * F * (16 * Pp + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * Pp + 2 * F + F * (D + 1)) * 4 + 16;
+}
 static inline bool conv0_fact_bwd_ok(const Geo& g) {
     if (g.Pp > 64 || g.D != 32) return false;
-    const size_t lds = (size_t)(4 * g.Pp * g.Pp + 2 * g.F * (16 * g.Pp + 16) + 4 * 16 * 32 + 2 * 32 * 16 + 4 * g.Pp + 2 * g.F +
-                                g.F * (g.D + 1)) * 4 + 16;
-    return lds <= 150 * 1024;
+    return conv0_fact_bwd_lds(g.Pp, g.F, g.D) <= 160 * 1024 - 512;
 }
 
 template <int NT>
 static int launch_conv0_fact_bwd(const DgradArgs& a, float* slabW, float* slabB, int64_t stride, int nsl, hipStream_t st) {
     constexpr int PP = NT * 16;
     constexpr int NW = 16;
-    const size_t lds = (size_t)(4 * PP * PP + 2 * a.F * (16 * PP + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * PP + 2 * a.F +
-                                a.F * (a.D + 1)) * 4 + 16;
+    const size_t lds = conv0_fact_bwd_lds(PP, a.F, a.D);
 #define CFFM_C0B_LAUNCH(FV, DV)                                                                                  \
     do {                                                                                                         \
         int rc = set_lds(conv0_fact_bwd_kernel<NT, FV, DV, NW>, lds);                                                \
@@ -3460,8 +3463,7 @@ int cffm_conv01_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, in
         (int64_t)a.n2 * CFFM_TOP_SLAB_ROWS < a.w2.Mtot || (int64_t)a.n3 * CFFM_TOP_SLAB_ROWS < a.w3.Mtot)
         return CFFM_ERR_UNSUPPORTED;             // one layer-0/1 slab per workgroup, the 64-row slabs cover layers 2 and 3
     const int NW = 16, PP = g.Pp;
-    const size_t lds = (size_t)(4 * PP * PP + 2 * g.F * (16 * PP + 16) + NW * 16 * 32 + 2 * 32 * 16 + NW * PP + 2 * g.F +
-                                g.F * (g.D + 1)) * 4 + 16;                     // the layer-0 phases; the weight gradients need 3 x 64*PP*4
+    const size_t lds = conv0_fact_bwd_lds(PP, g.F, g.D);       // the layer-0 phases; the weight gradients need 3 x 64*PP*4
 #define CFFM_C01_LAUNCH(NTV, FV, DV, ACTV)                                                                       \
     do {                                                                                                         \
         int rc = set_lds(conv01_bwd_kernel<NTV, FV, DV, ACTV>, lds);                                             \
