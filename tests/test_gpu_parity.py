@@ -101,6 +101,10 @@ CASES = {
     'f7-d32-b64-gelu': dict(M=600, F=7, K=8, D=32, act='gelu', B=64),
     'f5-d32-b200-relu': dict(M=400, F=5, K=32, D=32, act='relu', B=200),
     'f7-d32-b63-gelu': dict(M=600, F=7, K=8, D=32, act='gelu', B=63),
+    # the fused top followed by conv_bwd_pair_kernel with the deferred top-layer weight gradients (top_wgrad_deferred): 256
+    # examples at Pp = 64 (too wide for conv01_bwd_kernel) and at D = 64 (five conv layers)
+    'f11-d32-b256-relu': dict(M=800, F=11, K=8, D=32, act='relu', B=256),
+    'f6-d64-b256-elu': dict(M=500, F=6, K=8, D=64, act='elu', B=256),
 }
 HEAVY = [k for k, v in CASES.items() if v.get('heavy')]       # oracle needs several GB and ~a minute per pass
 LIGHT = [k for k in CASES if k not in HEAVY]
@@ -331,7 +335,8 @@ def test_backward_stages(name):
 TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
                'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
                'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
-               'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu']
+               'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu',
+               'f11-d32-b256-relu', 'f6-d64-b256-elu']
 
 
 @pytest.mark.parametrize('name,trained_like', [(n, t) for n in TRAIN_CASES for t in (True, False)] + [(n, True) for n in HEAVY])
