@@ -43,12 +43,15 @@ d = lambda a, b: float(np.median(R[:, b] - R[:, a]) * 10)
 print('bwd_top example role (ns): begin %d, loss %d, head example %d, head end %d, top wgrad %d, top dgrad %d, next wgrad %d, next dgrad %d | total %d'
       % (d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7), d(7, 8), d(0, 8)))
 print('bwd_top inner role (ns): loss %d, keys %d, inner bwd %d | total %d; starts %d after the example role' % (d(36, 37), d(37, 38), d(38, 39), d(36, 39), d(0, 36)))
-print('pair (ns): dgrad role %d, wgrad role %d; starts %d after bwd_top start' % (d(21, 22), d(23, 24), d(0, 21)))
-print('pair offsets from the dgrad role start (ns): wgrad role starts %d, ends %d; deferred top role starts %d, ends %d; dgrad ends %d' % (d(21, 23), d(21, 24), d(21, 30), d(21, 31), d(21, 22)))
-print('pair wgrad role, workgroup 7 (ns): loads issued + dC staged %d, MFMAs %d, slab stores issued %d' % (d(32, 33), d(33, 34), d(34, 24)))
-print('conv0_fact_bwd (ns): W+E load %d, A %d, B %d, C %d, D %d, E %d, rs+sync+reduce %d, F %d, tail %d | total %d; starts %d after pair'
-      % (d(12, 13), d(13, 14), d(14, 15), d(15, 16), d(16, 17), d(17, 18), d(18, 19), d(19, 20), d(20, 25), d(12, 25), d(21, 12)))
+fused01 = bool(R[:, 40].any())          # conv01_bwd_kernel ran (the frappe command): the pair launch and conv0_fact_bwd_kernel did not
+if not fused01:
+    print('pair (ns): dgrad role %d, wgrad role %d; starts %d after bwd_top start' % (d(21, 22), d(23, 24), d(0, 21)))
+    print('pair offsets from the dgrad role start (ns): wgrad role starts %d, ends %d; deferred top role starts %d, ends %d; dgrad ends %d' % (d(21, 23), d(21, 24), d(21, 30), d(21, 31), d(21, 22)))
+    print('pair wgrad role, workgroup 7 (ns): loads issued + dC staged %d, MFMAs %d, slab stores issued %d' % (d(32, 33), d(33, 34), d(34, 24)))
+print('%s (ns): W+E load %d, A %d, B %d, C %d, D %d, E %d, rs+sync+reduce %d, F %d, tail %d | total %d'
+      % ('layer-0 phases of conv01_bwd' if fused01 else 'conv0_fact_bwd', d(12, 13), d(13, 14), d(14, 15), d(15, 16), d(16, 17), d(17, 18), d(18, 19), d(19, 20), d(20, 25), d(12, 25)))
+if fused01:
+    print('conv01_bwd (ns): input gradient of layer 1 %d, weight gradients of layers 1-3 %d, layer 0 %d | total %d; starts %d after bwd_top start'
+          % (d(40, 41), d(41, 42), d(42, 25), d(40, 25), d(0, 40)))
 print('update_all (ns): reduce role %d, sparse role %d; starts %d after conv0_fact_bwd start; step span bwd_top start -> update end %d'
       % (d(26, 27), d(28, 29), d(12, 26), max(d(0, 27), d(0, 29))))
-print('conv01_bwd (ns), when that launch replaces the pair launch + conv0_fact_bwd: input gradient of layer 1 %d, weight gradients of layers 1-3 %d, layer 0 %d | total %d; starts %d after bwd_top start'
-      % (d(40, 41), d(41, 42), d(42, 25), d(40, 25), d(0, 40)))
