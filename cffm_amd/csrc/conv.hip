@@ -187,8 +187,10 @@ struct ConvArgs {
     int dbg;             // debug build only (make TILE_DBG=1): phase-skipping bits for tools/dbg_tile.py, 0 otherwise
 };
 
+// The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
+// accumulation registers = 2 per SIMD without the bound): 12.93 -> 12.33 ms per launch at the stress shape.
 template <int NT, int RM, bool GEN>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);                    // [2][32][LDW]
@@ -294,8 +296,10 @@ struct DgradArgs {
     int nblk;            // dgrad_kernel, L0 = false: column blocks of a row tile (1-D grid, see xcd_tile)
 };
 
+// 3 wavefronts per SIMD for the 128 x 128 instance (166 VGPRs instead of 200, nothing spilled): 16.36 -> 14.80 ms per launch at
+// the stress shape.  (wgrad2_kernel<8> at the same bound spills 189 registers and stays at 2.)
 template <int NT, int RM, bool L0>
-__global__ __launch_bounds__(256) void dgrad_kernel(DgradArgs a) {
+__global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgrad_kernel(DgradArgs a) {
     constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);
