@@ -16,9 +16,12 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 2048)()
 lib = hip.load()
 lib.cffm_debug_wg_times.argtypes = [C.c_void_p]
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-roles = {848: [('wgrad L1', 0, 256), ('top L3', 256, 272), ('top L2', 272, 336), ('dgrad', 336, 848)], 768: [('wgrad', 0, 256), ('dgrad', 256, 768)],
-         512: [('inner role', 0, 256), ('example role', 256, 512)]}[n]
+# usage: tools/wg_pair.py [top|pair848|pair768]
+which = sys.argv[1] if len(sys.argv) > 1 else 'top'
+roles = {'pair848': [('wgrad L1', 0, 256), ('top L3', 256, 272), ('top L2', 272, 336), ('dgrad', 336, 848)],
+         'pair768': [('wgrad', 0, 256), ('dgrad', 256, 768)],
+         'top': [('inner role', 0, 256), ('key placement', 256, 512), ('example role', 512, 768)]}[which]
+n = roles[-1][2]
 for i in range(3):
     eng.train_step(X[i % 8], y[i % 8]); torch.cuda.synchronize()
     lib.cffm_debug_wg_times(buf)
