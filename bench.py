@@ -108,63 +108,73 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def gather_roofline(device):
-    """The embedding-gather kernels on the stress shape of BASELINE.json configs[3] (32 fields, dim 64, 1 M features,
-    8192 rows, uniform ids: 516 MB of tables, beyond the Infinity Cache), timed with HIP events on the stream they are
-    launched on (torch's current stream).  achieved = ALGORITHMIC bytes (F*(K+D+1)*4 + F*4 per example) / time.
+    """The embedding gather on the stress shape of BASELINE.json configs[3] (32 fields, dim 64, 1 M features, 8192 rows,
+    uniform ids: 516 MB of tables, beyond the Infinity Cache), timed with HIP events on the stream the kernels are launched
+    on (torch's current stream).  achieved = ALGORITHMIC bytes (F*(K+D+1)*4 + F*4 per example) / time.
 
-    gather_packed_kernel   cffm_gather_packed: the owner side of a row-sharded lookup (ShardedStep), one packed record
-                           (inner | outer | bias) per id - the gather that is a launch of its own on a product path
-    gather_rows_kernel     cffm_gather: three separate outputs (the stage API / non-fused forward)
-    Both materialise their output, i.e. they write as many bytes as they read: see DESIGN.md for why the read-only form
-    (rows consumed in the kernel that fetches them) is VALU-bound, not HBM-bound, at this shape."""
-    M, F, K, D, B = 1000000, 32, 64, 64, 8192
+    gather_inner_fwd_wide_kernel   cffm_gather_inner_fwd: the PRODUCT-PATH gather of the wide shapes - the three lookups fused
+                                   with the inner branch, the s0 pool and the first-order inputs; rows go HBM -> LDS ->
+                                   registers and are never written back (what cffm_train_step / cffm_predict run at this
+                                   shape).  This is the roofline kernel.
+    gather_packed_kernel           cffm_gather_packed: owner side of a row-sharded lookup (materialises one packed record per id)
+    gather_rows_kernel             cffm_gather: three separate outputs (the stage API)"""
+    cfg, B = workload_cfg('syn1m')
+    M, F, K, D = cfg.M, cfg.F, cfg.K, cfg.D
     lib = hip.load()
-    shape = hip.Shape(M=M, F=F, K=K, D=D, act=0, linear_att=1, inner_conv=1, outer_conv=1, loss=0,
-                      lamda_att=1.0, beta_outer=1.0, lr=0.05)
-    g = torch.Generator(device=device).manual_seed(2021)
-    inner = torch.randn((M, K), device=device, generator=g)
-    outer = torch.randn((M, D), device=device, generator=g)
-    fbias = torch.randn((M,), device=device, generator=g)
-    tabs = hip.Tables(inner.data_ptr(), outer.data_ptr(), fbias.data_ptr())
+    eng = HipEngine(cfg, params='device', seed=2021, device=str(device))
+    eng.fbias.normal_(0.0, 0.3)                       # exactly 0 at init (CFFM.py:276): give the copy check something to see
     ids = torch.from_numpy(synth.sample_ids(np.random.default_rng(2021), M, F, B * 8)).to(device).reshape(8, B, F)
+    state = {'i': 0}
+
+    def run_fused():
+        i = state['i'] = (state['i'] + 1) % 8
+        eng.gather_inner_fwd(ids[i])
+    ms_fused = event_time_ms(run_fused, 40)
+    fb = eng.ws_tensor(B, 'fb', (B, F))
+    assert torch.equal(fb, eng.fbias[ids[state['i']].long()])
+    io = eng.ws_tensor(B, 'inner_out', (B,))
+    assert bool(torch.isfinite(io).all()) and float(io.abs().max()) > 0
+
+    shape, tabs = eng.shape, eng.tables
     Ei = torch.empty((B, F, K), device=device)
     Eo = torch.empty((B, F, D), device=device)
-    fb = torch.empty((B, F), device=device)
-    Wp = K + D + 4
-    packed = torch.empty((B * F, Wp), device=device)
+    fbo = torch.empty((B, F), device=device)
+    packed = torch.empty((B * F, K + D + 4), device=device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    state = {'i': 0}
 
     def run_rows():
         i = state['i'] = (state['i'] + 1) % 8
         hip.check(lib.cffm_gather(C.byref(shape), C.byref(tabs), C.c_void_p(ids[i].data_ptr()), B,
-                                  C.c_void_p(Ei.data_ptr()), C.c_void_p(Eo.data_ptr()), C.c_void_p(fb.data_ptr()), st))
+                                  C.c_void_p(Ei.data_ptr()), C.c_void_p(Eo.data_ptr()), C.c_void_p(fbo.data_ptr()), st))
 
     def run_packed():
         i = state['i'] = (state['i'] + 1) % 8
         hip.check(lib.cffm_gather_packed(C.byref(shape), C.byref(tabs), C.c_void_p(ids[i].data_ptr()), B * F,
                                          C.c_void_p(packed.data_ptr()), st))
     ms_rows = event_time_ms(run_rows, 40)
-    assert torch.equal(Eo[5], outer[ids[state['i']][5].long()])
+    assert torch.equal(Eo[5], eng.outer[ids[state['i']][5].long()])
     ms_packed = event_time_ms(run_packed, 40)
     idl = ids[state['i']].reshape(-1).long()
-    assert torch.equal(packed[:, K:K + D], outer[idl]) and torch.equal(packed[:, K + D], fbias[idl])
+    assert torch.equal(packed[:, K:K + D], eng.outer[idl]) and torch.equal(packed[:, K + D], eng.fbias[idl])
     bytes_per_launch = B * (F * (K + D + 1) * 4 + F * 4)
-    achieved = bytes_per_launch / (ms_packed * 1e-3) / 1e9
+    achieved = bytes_per_launch / (ms_fused * 1e-3) / 1e9
     traffic, source = None, None      # HBM bytes per launch: rocprofv3 PMC passes of this command, committed under profiles/
     try:
-        source = 'profiles/r02_gather_pmc.json'
+        source = 'profiles/r03_gather_pmc.json'
         with open(os.path.join(ROOT, source)) as fh:
-            traffic = int(json.load(fh)['gather_packed_kernel']['hbm_bytes_per_launch'])
+            traffic = int(json.load(fh)['gather_inner_fwd_wide_kernel']['hbm_bytes_per_launch'])
     except Exception:
         traffic, source = None, None
-    del inner, outer, fbias, Ei, Eo, fb, packed
+    del eng, Ei, Eo, fbo, packed
     torch.cuda.empty_cache()
-    return {'bound': 'hbm', 'kernel': 'gather_packed_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+    rate = lambda ms: round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)
+    return {'bound': 'hbm', 'kernel': 'gather_inner_fwd_wide_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
-            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms_packed * 1e3, 2),
-            'gather_rows_kernel': {'us_per_launch': round(ms_rows * 1e3, 2),
-                                   'achieved': round(bytes_per_launch / (ms_rows * 1e-3) / 1e9, 1)},
+            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms_fused * 1e3, 2),
+            'note': 'product-path kernel (cffm_train_step / cffm_predict at this shape): lookups fused with the inner branch, '
+                    'nothing materialised; VALU-bound, see DESIGN.md',
+            'gather_packed_kernel': {'us_per_launch': round(ms_packed * 1e3, 2), 'achieved': rate(ms_packed)},
+            'gather_rows_kernel': {'us_per_launch': round(ms_rows * 1e3, 2), 'achieved': rate(ms_rows)},
             'workload': 'synthetic libfm 32 fields dim 64 1M features batch 8192 uniform ids (tables 516 MB)'}
 
 

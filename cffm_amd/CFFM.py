@@ -244,6 +244,10 @@ class CFFM(object):
             raise ValueError('evaluate() needs at least one example')
         sums = self.engine.eval_sums(ids, y, lo, hi, block=max(int(self.batch_size), 8192))
         ss_res, sy, syy = (float(v) for v in sums.cpu().numpy())
+        if not math.isfinite(ss_res):
+            # np.maximum/np.minimum propagate NaN and sklearn's mean_squared_error raises on it (CFFM.py:607-612): a
+            # diverged model must not come back with a finite metric
+            raise ValueError('evaluate(): predictions contain NaN or infinity')
         RMSE = math.sqrt(ss_res / num_example)                  # sqrt(mean_squared_error), CFFM.py:610-612
         ss_tot = syy - sy * sy / num_example                    # sum (y - mean(y))^2
         R2 = 1.0 - ss_res / ss_tot if ss_tot > 0 else (1.0 if ss_res == 0 else 0.0)    # sklearn r2_score, CFFM.py:614

@@ -96,8 +96,17 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
     return 0;
 }
 
+// no_materialise: the composites that own the whole step (cffm_train_step, cffm_predict, cffm_dp_local) let the wide shapes
+// consume the looked-up rows in the kernel that fetches them (cffm_gather_inner_fwd_wide) and re-fetch them from the tables
+// where a later kernel needs them (backward_impl with the same tab / ids); ws.Ei / ws.Eo are then never written.
+// cffm_forward keeps materialising: its callers (the stage-by-stage parity tests, cffm_backward, the row-sharded step) read
+// ws.Ei / ws.Eo afterwards.
+static bool wide_rows(const cffm_shape_t* s, const cffm_tables_t* tab, const int32_t* ids) {
+    return tab && ids && cffm_wide_regather_ok(s);
+}
+
 static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
-                        const float* y, int32_t B, void* ws, bool fused_step, hipStream_t stream) {
+                        const float* y, int32_t B, void* ws, bool fused_step, hipStream_t stream, bool no_materialise = false) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -105,6 +114,14 @@ static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const f
     cffm_ws_layout(s, B, &wl);
     char* w = (char*)ws;
     const Geo g = make_geo(s);
+    if (no_materialise && wide_rows(s, tab, ids)) {
+        if ((rc = cffm_gather_inner_fwd_wide(s, tab, theta, ids, B, ws, stream))) return rc;
+        const RowSrc ro = {tab->outer_emb, ids, s->M};
+        if ((rc = cffm_outer_conv0_fwd_rows(s, theta, ws, B, &ro, stream))) return rc;
+        for (int l = 1; l < g.live; ++l)
+            if ((rc = cffm_conv_fwd(s, theta, ws, B, l, stream))) return rc;
+        return cffm_head_fwd_impl2(s, theta, ws, y, B, !fused_step, true, stream);
+    }
     if (!tab) {
         // row-sharded tables: the rows came in over the wire and are already staged in ws.Ei / ws.Eo / ws.fb
         if (fused_step) return CFFM_ERR_UNSUPPORTED;
@@ -134,7 +151,7 @@ extern "C" int cffm_forward(const cffm_shape_t* s, const cffm_tables_t* tab, con
 
 extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
                             int32_t B, void* ws, float* out, void* stream) {
-    int rc = cffm_forward(s, tab, theta, ids, nullptr, B, ws, stream);
+    int rc = forward_impl(s, tab, theta, ids, nullptr, B, ws, false, (hipStream_t)stream, true);
     if (rc || B <= 0) return rc;
     if (out) {
         cffm_ws_layout_t wl;
@@ -148,7 +165,8 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
 // backward through the slab reduction; fused = single-GPU step (local loss sum, Adagrad folded into the reduction)
 static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
                          int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream,
-                         bool unscaled = false, bool skip_reduce = false, const int32_t* rank_ids = nullptr) {
+                         bool unscaled = false, bool skip_reduce = false, const int32_t* rank_ids = nullptr,
+                         const cffm_tables_t* rtab = nullptr, const int32_t* rids = nullptr) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -161,6 +179,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
         if (e != hipSuccess) return (int)e;
     }
     bool inner_done = false;
+    const bool wide = wide_rows(s, rtab, rids);      // the forward did not materialise Ei / Eo: rows come from the tables (RowSrc)
     if (bwd_top_ok(s, B) && s->loss != CFFM_LOSS_SQUARE_L2) {
         // head + top two conv layers + inner branch: one launch
         int next = 0;
@@ -186,10 +205,24 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
                 else rc = cffm_conv_bwd(s, theta, ws, B, l, stream);
                 if (rc) return rc;
             }
-            if ((rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream))) return rc;
+            if (wide) {
+                const RowSrc ro = {rtab->outer_emb, rids, s->M};
+                rc = cffm_outer_conv0_bwd_rows(s, theta, ws, B, &ro, stream);
+            } else {
+                rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream);
+            }
+            if (rc) return rc;
         }
     }
-    if (!inner_done && (rc = cffm_inner_bwd(s, theta, ws, B, stream))) return rc;
+    if (!inner_done) {
+        if (wide) {
+            const RowSrc ri = {rtab->inner_emb, rids, s->M};
+            rc = cffm_inner_bwd_rows(s, theta, ws, B, &ri, stream);
+        } else {
+            rc = cffm_inner_bwd(s, theta, ws, B, stream);
+        }
+        if (rc) return rc;
+    }
     if (skip_reduce) return 0;                  // the caller reduces the slabs together with the table update
     return cffm_reduce_slabs_impl(s, ws, B, grad, fused ? theta : nullptr, fused ? theta_acc : nullptr, s->lr, stream);
 }
@@ -243,10 +276,10 @@ extern "C" int cffm_dp_local(const cffm_shape_t* s, const cffm_tables_t* tab, co
     const bool run = cffm_fwd_all_ok(s, B);          // false for a disabled branch: plain forward, no sorted run          // the single-launch forward also leaves this rank's keys sorted
     const bool later = run && defer_rank(s, B);
     if (run) rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later);
-    else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st);
+    else rc = forward_impl(s, tab, theta, ids, y, B, ws, false, st, true);
     if (rc) return rc;
     if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, st, true, true,
-                            later ? ids : nullptr))) return rc;
+                            later ? ids : nullptr, run ? nullptr : tab, run ? nullptr : ids))) return rc;
     return cffm_dp_tail(s, ids, B, ws, grad, rows, run, st);
 }
 
@@ -296,9 +329,9 @@ extern "C" int cffm_train_step(const cffm_shape_t* s, const cffm_tables_t* tab, 
             return rc;
         return cffm_update_all(s, tab, tab_acc, theta, theta_acc, grad, ws, B, st);
     }
-    rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st);
+    rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st, true);
     if (rc) return rc;
-    if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st))) return rc;
+    if ((rc = backward_impl(s, theta, theta_acc, y, B, (int64_t)B, ws, grad, true, loss, st, false, false, nullptr, tab, ids))) return rc;
     return cffm_sparse_adagrad_impl(s, tab, tab_acc, ids, (int64_t)B * s->F,
                                     s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
                                     s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),
@@ -316,9 +349,11 @@ extern "C" int cffm_train_step_opt(const cffm_shape_t* s, const cffm_tables_t* t
     if (B <= 0) return 0;
     if (s->loss == CFFM_LOSS_SQUARE_L2 && (!s->inner_conv || !s->outer_conv)) return CFFM_ERR_UNSUPPORTED;   // as in cffm_train_step
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st))) return rc;
+    const bool nm = s->loss != CFFM_LOSS_SQUARE_L2;      // the regularised loss sweeps the tables densely: keep its path as it was
+    if ((rc = forward_impl(s, tab, theta, ids, y, B, ws, true, st, nm))) return rc;
     // gradients only (no fused Adagrad); the loss is written by head_bwd
-    if ((rc = backward_impl(s, theta, nullptr, y, B, (int64_t)B, ws, grad, false, loss, st))) return rc;
+    if ((rc = backward_impl(s, theta, nullptr, y, B, (int64_t)B, ws, grad, false, loss, st, false, false, nullptr,
+                            nm ? tab : nullptr, nm ? ids : nullptr))) return rc;
     return cffm_apply_opt(s, tab, tab_state1, tab_state2, theta, theta_state1, theta_state2, grad, ids, (int64_t)B * s->F, ws,
                           B, step, st);
 }

@@ -77,6 +77,43 @@ static inline int check_shape(const cffm_shape_t* s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Where the looked-up rows of a [B,F] id batch are read from (tf.nn.embedding_lookup, CFFM.py:303, :354, :422).
+//   idx == nullptr  the copy a gather left in the workspace: row `slot` (= b*F + f) of base [B*F][dim]
+//   idx != nullptr  straight from the table: row clamp(idx[slot]) of base [M][dim].  The wide shapes (Pp > 64) run this
+//                   way: the fused gather + inner-branch forward consumes the rows in the kernel that fetches them and
+//                   nothing is materialised; the few later kernels that need a row again (the tiled layer 0, the
+//                   inner-branch backward) fetch it from the table - 67 MB of reads against 27-64 ms kernels.
+// ---------------------------------------------------------------------------------------------
+struct RowSrc {
+    const float* base;
+    const int32_t* idx;
+    int M;
+};
+__device__ __forceinline__ const float* row_ptr(const float* base, const int32_t* idx, int M, int64_t slot, int dim) {
+    if (idx == nullptr) return base + slot * dim;
+    int id = idx[slot];
+    id = id < 0 ? 0 : (id >= M ? M - 1 : id);               // clamp: a bad id must not fault the GPU
+    return base + (int64_t)id * dim;
+}
+// [F][D] rows of example b -> LDS tile Es[f * Dp + d] (the staging loop of the tiled layer-0 kernels)
+__device__ __forceinline__ void stage_example_rows(float* Es, const float* base, const int32_t* idx, int M, int b, int F, int D,
+                                                   int Dp, int tid, int nth) {
+    const float invD = 1.f / (float)D;
+    if (idx == nullptr) {
+        const float* e = base + (int64_t)b * F * D;
+        for (int i = tid; i < F * D; i += nth) {
+            const int f = (int)(((float)i + 0.5f) * invD), d = i - f * D;
+            Es[f * Dp + d] = e[i];
+        }
+    } else {
+        for (int i = tid; i < F * D; i += nth) {
+            const int f = (int)(((float)i + 0.5f) * invD), d = i - f * D;
+            Es[f * Dp + d] = row_ptr(base, idx, M, (int64_t)b * F + f, D)[d];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-K gradient slabs.  Every dense-gradient producer writes per-workgroup partial sums ("slabs") that
 // cffm_reduce_slabs adds up in slab order.  theta is cut into contiguous ranges, each with its own slab
 // count: the small head / inner ranges get one slab per example (up to 256), a conv layer gets CFFM_NSLAB or,

@@ -185,6 +185,8 @@ struct ConvArgs {
     int B, lgSo, P, Pp, F, D, act;
     int nblk;            // conv_fwd_kernel: column blocks of a row tile (the grid is 1-D, see xcd_tile)
     int dbg;             // debug build only (make TILE_DBG=1): phase-skipping bits for tools/dbg_tile.py, 0 otherwise
+    const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = `in` is the outer TABLE [M][D] and row (b, f) is idx[b*F+f] (RowSrc)
+    int idxM = 0;
 };
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
@@ -294,6 +296,8 @@ struct DgradArgs {
     int64_t Mtot;
     int B, lgSo, P, Pp, F, D, act, t1w, t1off;   // t1off: offset of this layer's input pool inside t1
     int nblk;            // dgrad_kernel, L0 = false: column blocks of a row tile (1-D grid, see xcd_tile)
+    const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = Cprev is the outer TABLE [M][D], row (b, f) = idx[b*F+f] (RowSrc)
+    int idxM = 0;
 };
 
 // 3 wavefronts per SIMD for the 128 x 128 instance (166 VGPRs instead of 200, nothing spilled): 16.36 -> 14.80 ms per launch at
@@ -529,6 +533,8 @@ struct WgradArgs {
     int64_t slab_stride, slabB_stride, Mtot;
     int B, lgSo, P, Pp, F, D, act, qblocks;
     int nslab, nxy;      // wgrad_kernel: gradient slabs and output tiles per slab (1-D grid, see xcd_tile)
+    const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = `in` is the outer TABLE [M][D], row (b, f) = idx[b*F+f] (RowSrc)
+    int idxM = 0;
 };
 
 // Generic form (64 x 16*NT output tile per workgroup): the direct layer 0 (GEN, F >= 33) and column-tile counts other than
@@ -2503,14 +2509,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
 #else
     constexpr int dbg = 0;
 #endif
-    {
-        const float* e = a.in + (int64_t)b * F * D;
-        const float invD = 1.f / (float)D;
-        for (int i = tid; i < F * D; i += NTH) {
-            const int f = fast_div(i, invD), d = i - f * D;
-            Es[f * Dp + d] = (dbg & 16) ? 1.f : e[i];
-        }
-    }
+    stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
     lds_barrier();
     // ---- step 1 -----------------------------------------------------------------------------------------------------
     // The kernel is instruction-issue-bound (with every load, MFMA and store switched off it still ran 11.6 of its 29.2 ms
@@ -2632,14 +2631,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_wgrad_kernel(Wgrad
     float bsum = 0.f;                                          // bias partial of channel q0 + (tid & 15), rows tid >> 4 (g == 0 only)
     for (int b = slab; b < a.B; b += nslab) {
         __syncthreads();                                       // previous example fully consumed
-        {
-            const float* e = a.in + (int64_t)b * F * D;
-            const float invD = 1.f / (float)D;
-            for (int i = tid; i < F * D; i += NTH) {
-                const int f = fast_div(i, invD), d = i - f * D;
-                Es[f * Dp + d] = e[i];
-            }
-        }
+        stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
         for (int xt = 0; xt < RT; ++xt) {
             const int x0 = xt * 16;
             if (xt > 0) __syncthreads();                       // dCt / dTg of the previous column tile consumed
@@ -2777,14 +2769,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
     float* rs = dTg + 4096;                                     // [F] row sums, [F] dots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x;
-    {
-        const float* e = a.Cprev + (int64_t)b * F * D;
-        const float invD = 1.f / (float)D;
-        for (int i = tid; i < F * D; i += NTH) {
-            const int f = fast_div(i, invD), d = i - f * D;
-            Es[f * Dp + d] = e[i];
-        }
-    }
+    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
     f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt)
@@ -3136,7 +3121,8 @@ static inline int t1_offset(const Geo& g, int l) {
     return off;
 }
 
-static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st) {
+static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st,
+                        const RowSrc* rs = nullptr) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -3174,7 +3160,11 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         return rc;
     }
     // rank-1 input channels: factorised, channel-tiled (its step 1 indexes k over ALL fields: 2 * ceil4(F) <= 64 k values)
-    if (l == 0 && conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS) return launch_conv0_fact_tile_fwd(a, st);
+    if (l == 0 && conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS) {
+        if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; }     // rows straight from the outer table (RowSrc)
+        return launch_conv0_fact_tile_fwd(a, st);
+    }
+    if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;                  // cffm_wide_regather_ok() guards the callers
     pick_nt(g.Pp / 16, &nblk, &NT);
     const bool big = a.Mtot >= 128 * 256;
     if (l == 0) {
@@ -3272,7 +3262,7 @@ int cffm_bwd_top_impl(const cffm_shape_t* s, const float* theta, void* ws, const
 // which: bit 0 = weight/bias gradient, bit 1 = input gradient (the two only share their inputs, so the fused
 // step runs them on different streams)
 static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, int l, hipStream_t st, int which = 3,
-                        bool* with_inner = nullptr, bool with_top_wgrad = false) {
+                        bool* with_inner = nullptr, bool with_top_wgrad = false, const RowSrc* rs = nullptr) {
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -3356,7 +3346,11 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             if (rc) return rc;
         } else {
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
-        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) { rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st); }
+        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) {
+            if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
+            rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st);
+        }
+        else if (l == 0 && rs) { rc = CFFM_ERR_UNSUPPORTED; }
         else if (l == 0) { DISPATCH_NT(NT, rc = (launch_wgrad<NT_, true>(a, st))); }
         else if (NT == 8) { rc = launch_wgrad2<8>(a, st); }               // 128 x 128 output tile per workgroup
         else if (NT == 6) { rc = launch_wgrad2<6>(a, st); }               // 128 x 96
@@ -3387,7 +3381,11 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             else { DISPATCH_NT4(nt4, rc = (launch_dgrad_taps<NT_, 1, false, 1>(a, st))); }
             return rc;
         }
-        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32 && 2 * g.F <= 64) return launch_conv0_fact_tile_dgrad(a, st);
+        if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32 && 2 * g.F <= 64) {
+            if (rs) { a.Cprev = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
+            return launch_conv0_fact_tile_dgrad(a, st);
+        }
+        if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;
         pick_nt(4 * g.Pp / 16, &nblk, &NT);
         const bool big = a.Mtot >= 128 * 256;
         if (l == 0) {
@@ -3424,6 +3422,22 @@ extern "C" int cffm_conv_fwd(const cffm_shape_t* s, const float* theta, void* ws
     if (B <= 0 || !s->outer_conv) return 0;
     if (layer < 1) return CFFM_ERR_BAD_SHAPE;
     return conv_fwd_any(s, theta, ws, B, layer, (hipStream_t)stream);
+}
+// Wide shapes whose layer 0 runs the three tiled factorised kernels: those can take the outer rows straight from the table
+// (RowSrc), so the fused gather + inner-branch forward never writes Ei / Eo (cffm_gather_inner_fwd_wide, inner.hip)
+bool cffm_wide_regather_ok(const cffm_shape_t* s) {
+    if (check_shape(s) || !s->inner_conv || !s->outer_conv) return false;
+    const Geo g = make_geo(s);
+    return conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS && g.D / 2 <= 32 && 2 * g.F <= 64 &&
+           g.K == g.D && (g.K == 32 || g.K == 64) && g.F <= 32;
+}
+int cffm_outer_conv0_fwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st) {
+    if (B <= 0 || !s->outer_conv) return 0;
+    return conv_fwd_any(s, theta, ws, B, 0, st, rs);
+}
+int cffm_outer_conv0_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st) {
+    if (B <= 0 || !s->outer_conv) return 0;
+    return conv_bwd_any(s, theta, ws, B, 0, st, 3, nullptr, false, rs);
 }
 extern "C" int cffm_outer_conv0_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {
     int rc = check_shape(s);

@@ -17,7 +17,11 @@ __global__ __launch_bounds__(256) void eval_partial_kernel(const float* __restri
     __shared__ double red[3][4];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)EVAL_BLOCKS * 256) {
-        const float p = fminf(fmaxf(pred[i], lo), hi);          // np.maximum(..., min) then np.minimum(..., max)
+        // np.maximum(..., min) then np.minimum(..., max), which PROPAGATE NaN (fmaxf/fminf would map a NaN prediction to
+        // lo and a diverged model would report a finite, plausible RMSE): the sums then become NaN, as sklearn's metrics
+        // would refuse the reference's NaN predictions (CFFM.py:607-614)
+        const float raw = pred[i];
+        const float p = raw != raw ? raw : fminf(fmaxf(raw, lo), hi);
         const double yt = (double)y[i], d = yt - (double)p;
         s0 += d * d; s1 += yt; s2 += yt * yt;
     }

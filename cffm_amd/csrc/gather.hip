@@ -126,12 +126,24 @@ int cffm_pack_rows(const cffm_shape_t* s, const int32_t* ids, int32_t B, const f
 // in the same lanes instead of a scalar gather of its own.
 extern "C" int32_t cffm_packed_row_floats(const cffm_shape_t* s) { return s ? s->K + s->D + 4 : 0; }
 
+// g -> (g / CH, g % CH) without the 64-bit integer division sequence, for 0 <= g < 2^31 and 1 <= CH <= 2^12.  inv_ch must be
+// the DOUBLE reciprocal 1.0 / CH (relative error 2^-53): the product (g + 0.5) * inv_ch is then within 2^-21 of the true
+// quotient, which is itself at least 0.5 / CH >= 2^-13 away from every integer, so the truncation is exact; the +-1 correction
+// is a belt on top.  (A float reciprocal widened to double has a relative error of 6e-8 and is wrong by more than 1 near 2^30:
+// tests/test_abi.py::test_div_chunks_guard_boundary replays this arithmetic on the host.)
+__host__ __device__ __forceinline__ void div_chunks(int64_t g, int CH, double inv_ch, int64_t* slot, int* ch) {
+    int64_t q = (int64_t)(((double)g + 0.5) * inv_ch);
+    int r = (int)(g - q * CH);
+    if (r < 0) { --q; r += CH; } else if (r >= CH) { ++q; r -= CH; }
+    *slot = q; *ch = r;
+}
+
 template <int UNROLL>
 __global__ __launch_bounds__(256) void gather_packed_kernel(const float* __restrict__ inner, const float* __restrict__ outer,
                                                             const float* __restrict__ fbias, const int32_t* __restrict__ rows,
                                                             int64_t n, int K4, int D4, int M, float* __restrict__ out) {
     const int CH = K4 + D4 + 1;
-    const float inv_ch = 1.f / (float)CH;
+    const double inv_ch = 1.0 / (double)CH;                      // a TRUE double reciprocal: see div_chunks()
     const int64_t total = n * CH, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += stride * UNROLL) {
         f32x4 v[UNROLL];
@@ -141,10 +153,8 @@ __global__ __launch_bounds__(256) void gather_packed_kernel(const float* __restr
             const int64_t g = g0 + u * stride;
             ok[u] = g < total;
             if (ok[u]) {
-                // g / CH without the 64-bit division sequence: exact for the < 2^31 chunk counts one launch sees
-                int64_t slot = (int64_t)(((double)g + 0.5) * (double)inv_ch);
-                int ch = (int)(g - slot * CH);
-                if (ch < 0) { --slot; ch += CH; } else if (ch >= CH) { ++slot; ch -= CH; }
+                int64_t slot; int ch;
+                div_chunks(g, CH, inv_ch, &slot, &ch);
                 int id = rows[slot];
                 id = id < 0 ? 0 : (id >= M ? M - 1 : id);        // clamp: a bad id must not fault the GPU
                 if (ch < K4) v[u] = *(reinterpret_cast<const f32x4*>(inner) + (int64_t)id * K4 + ch);
@@ -180,12 +190,11 @@ __global__ __launch_bounds__(256) void stage_packed_kernel(const float* __restri
                                                            int64_t n_slots, int64_t n_records, int K4, int D4,
                                                            float* __restrict__ Ei, float* __restrict__ Eo, float* __restrict__ fb) {
     const int CH = K4 + D4 + 1;
-    const float inv_ch = 1.f / (float)CH;
+    const double inv_ch = 1.0 / (double)CH;
     const int64_t total = n_slots * CH, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        int64_t slot = (int64_t)(((double)g + 0.5) * (double)inv_ch);
-        int ch = (int)(g - slot * CH);
-        if (ch < 0) { --slot; ch += CH; } else if (ch >= CH) { ++slot; ch -= CH; }
+        int64_t slot; int ch;
+        div_chunks(g, CH, inv_ch, &slot, &ch);
         int64_t r = pos ? (int64_t)pos[slot] : slot;
         r = r < 0 ? 0 : (r >= n_records ? n_records - 1 : r);
         const f32x4 v = *(reinterpret_cast<const f32x4*>(packed) + r * CH + ch);

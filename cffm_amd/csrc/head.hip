@@ -44,6 +44,11 @@ extern "C" int cffm_head_fwd(const cffm_shape_t* s, const float* theta, void* ws
 
 int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum,
                        hipStream_t stream) {
+    return cffm_head_fwd_impl2(s, theta, ws, y, B, do_sum, false, stream);
+}
+
+int cffm_head_fwd_impl2(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum, bool s0_ready,
+                        hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -63,6 +68,7 @@ int cffm_head_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, cons
     a.t1 = (float*)(w + wl.t1); a.h1 = (float*)(w + wl.h1); a.att = (float*)(w + wl.att);
     a.out = (float*)(w + wl.out); a.sqerr = (float*)(w + wl.sqerr);
     a.loss = s->loss; a.inner_conv = s->inner_conv; a.outer_conv = s->outer_conv;
+    a.s0_ready = (s0_ready && s->outer_conv && s->D <= 256) ? 1 : 0;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), head_fwd_lds(a.g), (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     if (y && do_sum) {

@@ -13,6 +13,7 @@ struct HeadArgs {
     const float* y;           // may be NULL
     float *t1, *h1, *att, *out, *sqerr;
     int loss, inner_conv, outer_conv;
+    int s0_ready = 0;         // 1: t1[b][0:D] already holds the s0 pool (cffm_gather_inner_fwd_wide wrote it) and Eo is not read
 };
 
 __device__ __forceinline__ float loss_term(float out_raw, float y, int loss, float* out_eval) {
@@ -88,10 +89,12 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             yv = a.y ? a.y[b] : 0.f;
         }
     }
-    if (a.outer_conv) {
+    if (a.outer_conv && !a.s0_ready) {
         const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
         for (int i = tid; i < g.F * g.D / 4; i += NTH) reinterpret_cast<float4*>(Et)[i] = E4[i];
     }
+    float s0v = 0.f;                                                 // s0_ready: this thread's element of the pool, requested now
+    if (a.outer_conv && a.s0_ready && tid < g.D) s0v = a.t1[(int64_t)b * t1w + tid];
     if (wave == FO) {                                                // first-order term, :422-446 (needs nothing from the other waves)
         float lin;
         if (g.linear_att) {
@@ -148,6 +151,9 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         PHASE_MARK3(2);
         lds_barrier();                                             // Et (and the pools) are in LDS
         PHASE_MARK3(3);
+        if (a.s0_ready) {                                            // kernel-uniform: every thread takes the same side
+            if (tid < g.D) t1s[tid] = s0v;                           // (g.D <= 256 <= NTH on this path: the tiled layer 0 has D <= 64)
+        } else {
         for (int f = wave; f < g.F; f += NW) {                      // row sums of the embedding tile
             float s = 0.f;
             for (int d = lane; d < g.D; d += 64) s += Et[f * g.D + d];
@@ -163,6 +169,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
                 s += Et[i * g.D + h] * R;
             }
             t1s[h] = s;
+        }
         }
         lds_barrier();
         PHASE_MARK3(4);

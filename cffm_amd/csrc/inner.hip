@@ -50,6 +50,10 @@ int cffm_inner_fwd_impl(const cffm_shape_t* s, const float* theta, void* ws, int
 }
 
 extern "C" int cffm_inner_bwd(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, void* stream) {
+    return cffm_inner_bwd_rows(s, theta, ws, B, nullptr, (hipStream_t)stream);
+}
+
+int cffm_inner_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0 || !s->inner_conv) return 0;
@@ -64,7 +68,315 @@ extern "C" int cffm_inner_bwd(const cffm_shape_t* s, const float* theta, void* w
     }
     InnerBwdArgs a;
     const int nslab = fill_inner_bwd_args(s, theta, ws, B, &a);
+    if (rs) { a.Ei = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
     hipLaunchKernelGGL(inner_bwd_kernel, dim3(nslab), dim3(256), lds, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide shapes (Pp > 64; BASELINE configs[3]/[4]: F32 K64 D64): tf.nn.embedding_lookup x3 (CFFM.py:303, :354, :422) fused
+// with everything that consumes a whole looked-up example in one pass - the inner branch (:304-343), the s0 sum pool of the
+// outer-product map (:381, in closed form) and the first-order inputs (:422) - so that the rows go HBM -> LDS -> registers
+// and are never written back (the materialising gather of rounds 1-2 wrote as many bytes as it read).
+//
+// One workgroup of 1024 threads per CU.  Examples are taken E = 4 at a time ("phase"); the rows of the next phase (E x F x
+// (K + D) floats = 64 KB at F32 K64 D64) are in flight - global_load_dwordx4 into registers, 16 lanes = one 256-byte row,
+// ids fetched a phase earlier - while the current phase is computed out of LDS, so 64 KB per CU stay in flight behind the
+// VALU work (tools/probe_gather.hip: this access shape alone reads at 0.73 of 8 TB/s on this box).
+//
+// Inner branch: thread (g, t) = (tid / K2, tid % K2) owns the units (p, t) of pairs p = g*UPT .. g*UPT+UPT-1 for EVERY
+// example, so its 2 x UPT dense(1) weights and the LDS offsets of its rows live in registers for the whole kernel (the old
+// kernel re-read the 127 KB weight vector from L2 for every example).  Per unit: ds_read_b64 x2, then 10 VALU instructions,
+// 4 of them packed (v_pk_mul / v_pk_fma / v_pk_add on the (k, k+1) / (ch0, ch1) pairs).
+// The kernel is VALU-bound at this shape, not HBM-bound: 8192 x 496 x 32 units x 10 instructions = 1.3 G lane-instructions
+// against the ~46 T/s this box issues (tools/probe_gather.hip, v_fma_f32 on every SIMD) = 28 us, the 136 MB at the
+// measured gather rate 23 us.
+//
+// LDS image of one example: [F][K] inner rows, [F][D] outer rows = the pieces in fetch order (piece q at byte 16*q).
+// ---------------------------------------------------------------------------------------------------------------------
+#define GIW_E 4            // examples per phase
+#define GIW_T 1024         // threads per workgroup
+
+struct GatherInnerWideArgs {
+    const float *inner, *outer, *fbias;     // tables [M][K], [M][D], [M]
+    const int32_t* ids;                     // [B][F]
+    const float *cw, *cb, *wd, *bd;         // inner-branch parameters (theta)
+    float *inner_out, *t1, *fb;             // [B], [B][t1w] (columns 0..D-1 = s0), [B][F]
+    unsigned long long* keys;               // [B*F] packed (id << 32 | slot) for the sparse update (may be NULL)
+    int B, M, F, K, D, P, t1w, act;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the D4 (8 or 16) consecutive lanes that hold one row, on the DPP path; every lane of the group ends with it
+template <bool SIXTEEN>
+__device__ __forceinline__ float row_group_sum(float v) {
+    v += dpp_mov<0xB1, 0xf>(v, 0.f);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v, 0.f);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v, 0.f);    // row_half_mirror: 8 lanes
+    if (SIXTEEN) v += dpp_mov<0x140, 0xf>(v, 0.f);   // row_mirror: 16 lanes
+    return v;
+}
+
+// FS > 0: the field count as a compile-time constant (with K == D == 2*K2 this fixes the LDS image: every per-example offset of
+// the unit loop becomes an immediate of its ds_read_b64 instead of a v_add per read)
+template <int K2, int UPT, int ACTC, int FS>
+__global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInnerWideArgs a) {
+    constexpr int E = GIW_E, T = GIW_T, K = 2 * K2, NG = T / K2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = FS > 0 ? FS : a.F, D = FS > 0 ? K : a.D, P = FS > 0 ? FS * (FS - 1) / 2 : a.P, act = ACTC >= 0 ? ACTC : a.act;
+    const int K4 = K >> 2, D4 = D >> 2;
+    const int npiece = F * (K4 + D4);                        // 16-byte pieces of one example (<= T)
+    const int slot_bytes = npiece * 16;                      // LDS image of one example (<= 16 KB)
+    constexpr int buf_bytes = 65536;                         // the two row buffers sit at LDS addresses 0 and 64 KB (see the unit loop)
+    char* rows = smem;                                       // [2 buffers][E][slot]
+    float* RS = reinterpret_cast<float*>(smem + 2 * buf_bytes);   // [2][E][32] row sums of the outer rows
+    float* red = RS + 2 * E * 32;                            // [2][16 waves][E] inner_out partials
+    uint32_t* lut = reinterpret_cast<uint32_t*>(red + 2 * 16 * E);   // [NG * UPT] pair -> (i | j << 16)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nphase = (a.B + E - 1) / E;
+
+    // ---- per-thread constants: its units' weights and LDS offsets ----------------------------------------------------
+    for (int i = tid; i < F; i += T) {
+        const int base = i * (2 * F - i - 1) / 2;
+        for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
+    }
+    for (int p = P + tid; p < NG * UPT; p += T) lut[p] = 0u;
+    const int g = tid / K2, t = tid - g * K2;
+    f32x2 w[UPT];
+    uint32_t off[UPT];                                       // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
+    const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const int p = g * UPT + k;
+        w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
+    }
+    const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
+    const float bd = a.bd[0];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
+        off[k] = (uint32_t)(((int)(ij & 0xffff) * K + 2 * t) * 4) | ((uint32_t)(((int)(ij >> 16) * K + 2 * t) * 4) << 16);
+    }
+    // the unit loop forms LDS addresses as (offset | buffer << 16): dynamic LDS starts at address 0 in a kernel without
+    // static __shared__ variables
+    if ((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+
+    // ---- fetch role of this thread: piece q = tid of each of the E examples of a phase ------------------------------
+    const bool fetch = tid < npiece;
+    const bool is_in = tid < F * K4;
+    const int fq = is_in ? tid / K4 : (tid - F * K4) / D4;                // field of the piece
+    const int cq = is_in ? tid - fq * K4 : (tid - F * K4) - fq * D4;      // 16-byte piece inside the row
+    const float* tbl = is_in ? a.inner : a.outer;
+    const int rowlen4 = is_in ? K4 : D4;
+    // first-order role (:422): the thread that fetches the FIRST piece of an inner row also fetches feature_bias of that id and
+    // writes ws.fb / the sort key of the slot - with the id it already holds, so no dependent load sits in a phase
+    const bool fo_on = fetch && is_in && cq == 0;
+    int idn[E];                                                           // ids of the phase whose rows are fetched next
+    auto load_ids = [&](int ph) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int b = ph * E + e;
+            b = b < a.B ? b : a.B - 1;                                     // tail: a harmless duplicate
+            idn[e] = a.ids[(int64_t)b * F + fq];                           // raw: clamped where an address is formed
+        }
+    };
+    auto clampid = [&](int id) { return id < 0 ? 0 : (id >= a.M ? a.M - 1 : id); };   // a bad id must not fault the GPU
+    float fbn[E];                                                          // feature_bias of the phase being fetched (fo_on threads)
+    int rawn[E];
+    // rows go HBM -> LDS directly (global_load_lds_dwordx4: the wave's 64 pieces land as 1 KB at a wave-uniform LDS base +
+    // 16 * lane, which IS the image layout), so no staging registers are held across the compute phase
+    auto load_rows = [&](int buf) {
+        if (fetch) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1)))*)(reinterpret_cast<const f32x4*>(tbl) + (int64_t)clampid(idn[e]) * rowlen4 + cq),
+                    (void __attribute__((address_space(3)))*)(rows + buf * buf_bytes + e * slot_bytes + wave * 1024), 16, 0, 0);
+        }
+        if (fo_on) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { rawn[e] = idn[e]; fbn[e] = a.fbias[clampid(idn[e])]; }
+        }
+    };
+    // once the wave's own loads have landed (vmcnt(0)): row sums of the outer rows for the s0 pool - D4 lanes hold one row
+    auto row_sums = [&](int buf, int phn) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fo_on) {                                                       // first-order inputs + sort keys of phase phn
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int b = phn * E + e;
+                if (b < a.B) {
+                    const int64_t slot = (int64_t)b * F + fq;
+                    a.fb[slot] = fbn[e];
+                    if (a.keys) a.keys[slot] = ((unsigned long long)(unsigned)((rawn[e] < 0 || rawn[e] >= a.M) ? a.M : rawn[e]) << 32) | (unsigned long long)slot;   // bad id -> key M
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (fetch) v = *reinterpret_cast<const f32x4*>(rows + buf * buf_bytes + e * slot_bytes + tid * 16);
+            float s = (v.x + v.y) + (v.z + v.w);
+            s = D4 == 16 ? row_group_sum<true>(s) : row_group_sum<false>(s);
+            if (fetch && !is_in && cq == 0) RS[(buf * E + e) * 32 + fq] = s;
+        }
+    };
+
+    int ph = blockIdx.x;
+    if (ph < nphase) {
+        if (fetch) load_ids(ph);
+        load_rows(0);
+        if (ph + (int)gridDim.x < nphase && fetch) load_ids(ph + gridDim.x);
+        row_sums(0, ph);
+    }
+    __syncthreads();
+    int par = 0;
+    for (; ph < nphase; ph += gridDim.x, par ^= 1) {
+        const int nxt = ph + gridDim.x;
+        const bool more = nxt < nphase;
+        if (more) {
+            load_rows(par ^ 1);                                            // next phase's rows: in flight across the compute below
+            if (nxt + (int)gridDim.x < nphase && fetch) load_ids(nxt + gridDim.x);
+        }
+        // ---- inner branch of the E examples of this phase ------------------------------------------------------------
+        const char* buf = rows + par * buf_bytes;
+        f32x2 acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            // two instructions per unit address pair: v_and_or_b32 and v_alignbit_b32 put the buffer bit on top of the 16-bit offsets
+            const uint32_t ai = (off[k] & 0xffffu) | ((uint32_t)par << 16);
+            const uint32_t aj = __builtin_amdgcn_alignbit((uint32_t)par, off[k], 16);
+            typedef const f32x2 __attribute__((address_space(3))) * lds2_t;
+            f32x2 ei[E], ej[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ei[e] = *(lds2_t)(size_t)(ai + e * slot_bytes);
+                ej[e] = *(lds2_t)(size_t)(aj + e * slot_bytes);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                f32x2 x = ei[e] * ej[e];                                   // :310
+                x.x = act_f(x.x, act); x.y = act_f(x.y, act);              // :319
+                f32x2 z = __builtin_elementwise_fma((f32x2){x.x, x.x}, w0, cb2);      // :327  cw[tap*2+ch]
+                z = __builtin_elementwise_fma((f32x2){x.y, x.y}, w1, z);
+                const float mp = fmaxf(x.x, x.y);                          // :331
+                f32x2 c;
+                c.x = act_pos(fmaxf(z.x, 0.f), act); c.y = act_pos(fmaxf(z.y, 0.f), act);   // :478, :330
+                const f32x2 sv = c + (f32x2){mp, mp};                      // :332
+                acc[e] = __builtin_elementwise_fma(sv, w[k], acc[e]);      // :339
+            }
+            // keep the compiler from hoisting the LDS reads of ALL units to the top of the phase and sinking the arithmetic
+            // below them (it did: 267 spilled registers under the 128-register budget of a 1024-thread workgroup): the
+            // accumulators are pinned here, and nothing is scheduled across; the other three waves of the SIMD cover the
+            // LDS latency of this one
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+            static_assert(E == 4, "the pin above names the four accumulators");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float v = wave_sum(acc[e].x + acc[e].y);
+            if (lane == 0) red[(par * 16 + wave) * E + e] = v;
+        }
+        // ---- s0 pool (:381): s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]).  All 1024 threads: (example, h, quarter
+        // of the i range); a thread starts from the suffix sum at the top of its quarter, the four quarters meet in a quad sum
+        {
+            const int e = tid >> 8, h = (tid >> 2) & 63, part = tid & 3;
+            const int b = ph * E + e;
+            const float* Eo = reinterpret_cast<const float*>(buf + e * slot_bytes) + F * K;
+            const float* rs = RS + (par * E + e) * 32;
+            const int IP = (F - 1 + 3) >> 2;                               // i = 0 .. F-2 in four quarters
+            const int i_lo = part * IP, i_hi = min(i_lo + IP, F - 1) - 1;
+            float s = 0.f;
+            if (h < D && i_hi >= i_lo) {
+                float R = 0.f;
+                for (int j = F - 1; j > i_hi; --j) R += rs[j];
+                for (int i = i_hi; i >= i_lo; --i) {
+                    s += Eo[i * D + h] * R;
+                    R += rs[i];
+                }
+            }
+            s += dpp_mov<0xB1, 0xf>(s, 0.f);                               // quad_perm [1,0,3,2]
+            s += dpp_mov<0x4E, 0xf>(s, 0.f);                               // quad_perm [2,3,0,1]
+            if (part == 0 && h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
+        }
+        if (more) row_sums(par ^ 1, nxt);                                  // waits for the rows that were in flight
+        __syncthreads();
+        if (tid < E) {                                                     // inner_out of this phase: wavefront partials in wave order
+            const int b = ph * E + tid;
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 16; ++wv) s += red[(par * 16 + wv) * E + tid];
+            if (b < a.B) a.inner_out[b] = s + bd;                          // :339
+        }
+    }
+}
+
+template <int K2, int UPT, int ACTC, int FS>
+static int launch_giw1(const GatherInnerWideArgs& a, int grid, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute((const void*)gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS>), dim3(grid), dim3(GIW_T), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+template <int K2, int UPT>
+static int launch_giw(const GatherInnerWideArgs& a, int grid, size_t lds, hipStream_t st) {
+    if (K2 == 32 && UPT == 16 && a.F == 32 && a.D == 64) {          // BASELINE configs[3] / [4]: F32 K64 D64
+        if (a.act == CFFM_ACT_RELU) return launch_giw1<32, 16, CFFM_ACT_RELU, 32>(a, grid, lds, st);
+        return launch_giw1<32, 16, -1, 32>(a, grid, lds, st);
+    }
+    if (a.act == CFFM_ACT_RELU) return launch_giw1<K2, UPT, CFFM_ACT_RELU, 0>(a, grid, lds, st);
+    return launch_giw1<K2, UPT, -1, 0>(a, grid, lds, st);
+}
+
+int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,
+                               void* ws, hipStream_t stream) {
+    if (!cffm_wide_regather_ok(s) || !tab || !ids) return CFFM_ERR_UNSUPPORTED;
+    if (B <= 0) return 0;
+    cffm_theta_layout_t tl; cffm_ws_layout_t wl;
+    cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
+    const Geo g = make_geo(s);
+    char* w = (char*)ws;
+    GatherInnerWideArgs a;
+    a.inner = tab->inner_emb; a.outer = tab->outer_emb; a.fbias = tab->feat_bias; a.ids = ids;
+    a.cw = theta + tl.inner_cw; a.cb = theta + tl.inner_cb; a.wd = theta + tl.inner_dw; a.bd = theta + tl.inner_db;
+    a.inner_out = (float*)(w + wl.inner_out); a.t1 = (float*)(w + wl.t1); a.fb = (float*)(w + wl.fb);
+    a.keys = (unsigned long long*)(w + wl.sort_keys);
+    a.B = B; a.M = s->M; a.F = g.F; a.K = g.K; a.D = g.D; a.P = g.P; a.t1w = 2 * g.D - 2; a.act = g.act;
+    const int K2 = g.K / 2, NG = GIW_T / K2;
+    const int upt = (g.P + NG - 1) / NG;                       // pairs per thread group
+    const int npiece = g.F * (g.K / 4 + g.D / 4);
+    if (npiece > GIW_T || g.D > 64 || g.F > 32 || GIW_E * 256 != GIW_T) return CFFM_ERR_UNSUPPORTED;
+    const int nphase = (B + GIW_E - 1) / GIW_E;
+    int grid = nphase < 256 ? nphase : 256;                    // one workgroup per CU, phases dealt round-robin
+    int uptT = upt <= 4 ? 4 : (upt <= 8 ? 8 : 16);
+    if (upt > 16) return CFFM_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * 65536 + (size_t)(2 * GIW_E * 32 + 2 * 16 * GIW_E + NG * uptT) * 4;
+    if (K2 == 32) {
+        if (uptT == 4) return launch_giw<32, 4>(a, grid, lds, stream);
+        if (uptT == 8) return launch_giw<32, 8>(a, grid, lds, stream);
+        return launch_giw<32, 16>(a, grid, lds, stream);
+    }
+    if (K2 == 16) {
+        if (uptT == 4) return launch_giw<16, 4>(a, grid, lds, stream);
+        if (uptT == 8) return launch_giw<16, 8>(a, grid, lds, stream);
+        return launch_giw<16, 16>(a, grid, lds, stream);
+    }
+    return CFFM_ERR_UNSUPPORTED;
+}
+
+extern "C" int cffm_gather_inner_fwd_ok(const cffm_shape_t* s) { return cffm_wide_regather_ok(s) ? 1 : 0; }
+extern "C" int cffm_gather_inner_fwd(const cffm_shape_t* s, const cffm_tables_t* t, const float* theta, const int32_t* ids,
+                                     int32_t B, void* ws, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (!t || !theta || !ids || !ws) return CFFM_ERR_BAD_SHAPE;
+    return cffm_gather_inner_fwd_wide(s, t, theta, ids, B, ws, (hipStream_t)stream);
 }

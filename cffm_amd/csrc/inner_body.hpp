@@ -143,6 +143,8 @@ struct InnerBwdArgs {
     float* dEi;
     float *slab_cw, *slab_cb, *slab_dw, *slab_db;     // slab 0
     int64_t slab_stride;
+    const int32_t* idx = nullptr;                     // non-NULL: Ei is the inner TABLE [M][K] and row (b, f) is idx[b*F+f] (RowSrc)
+    int idxM = 0;
 };
 static inline size_t inner_bwd_lds(const Geo& g) { return (size_t)(5 * g.F * g.K + g.Pp + 8) * 4; }
 
@@ -186,8 +188,18 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
         // dL/dout of the example: its loads are in flight together with the embedding rows
         const float db = dout ? dout[b] : head_dout(a.loss, a.out[b], a.y[b], a.invB, L);
         __syncthreads();
-        const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * FK);
-        for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
+        if (a.idx == nullptr) {
+            const float4* src = reinterpret_cast<const float4*>(Ei + (int64_t)b * FK);
+            for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) reinterpret_cast<float4*>(E)[i] = src[i];
+        } else {                                       // wide shapes: the rows were never materialised, fetch them from the table
+            const int K4 = g.K >> 2;
+            const float invK4 = 1.f / (float)K4;
+            for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) {
+                const int f = fast_div(i, invK4), c = i - f * K4;
+                reinterpret_cast<float4*>(E)[i] =
+                    reinterpret_cast<const float4*>(row_ptr(Ei, a.idx, a.idxM, (int64_t)b * g.F + f, g.K))[c];
+            }
+        }
         for (int i = threadIdx.x; i < 4 * FK; i += blockDim.x) dE[i] = 0.f;
         __syncthreads();
         float* myE = dE + wave * FK;
@@ -268,7 +280,7 @@ static inline int fill_inner_bwd_args(const cffm_shape_t* s, const float* theta,
     a.Ei = (const float*)(w + wl.Ei); a.dout = (const float*)(w + wl.dout);
     a.out = (const float*)(w + wl.out); a.y = nullptr; a.loss = s->loss; a.invB = 1.f / (float)B;
     a.cw = theta + tl.inner_cw; a.cb = theta + tl.inner_cb; a.wd = theta + tl.inner_dw;
-    a.dEi = (float*)(w + wl.dEi);
+    a.dEi = (float*)(w + wl.dEi); a.idx = nullptr; a.idxM = 0;
     a.slab_cw = base + tl.inner_cw; a.slab_cb = base + tl.inner_cb; a.slab_dw = base + tl.inner_dw; a.slab_db = base + tl.inner_db;
     a.slab_stride = sr.len;
     return sr.nslab;

@@ -66,3 +66,16 @@ int cffm_tables_adagrad_l2(const cffm_shape_t* s, const cffm_tables_t* tab, cons
 int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* st1, const cffm_tables_t* st2,
                    float* theta, float* th1, float* th2, const float* grad, const int32_t* ids, int64_t n_rows, void* ws,
                    int32_t B_ws, int64_t step, hipStream_t st);
+
+// ---- wide shapes (Pp > 64): rows consumed where they are fetched, nothing materialised (RowSrc, common.hpp) ---------------
+bool cffm_wide_regather_ok(const cffm_shape_t* s);
+// tf.nn.embedding_lookup x3 fused with the inner branch, the s0 pool and the first-order inputs: ids -> ws.inner_out,
+// ws.t1[:, 0:D] (s0), ws.fb, ws.sort_keys; Ei / Eo are NOT written
+int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,
+                               void* ws, hipStream_t st);
+int cffm_outer_conv0_fwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);
+int cffm_outer_conv0_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);
+int cffm_inner_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);
+// s0_ready: ws.t1[:, 0:D] already holds the s0 pool (the fused gather computed it): ws.Eo is not read
+int cffm_head_fwd_impl2(const cffm_shape_t* s, const float* theta, void* ws, const float* y, int32_t B, bool do_sum, bool s0_ready,
+                        hipStream_t st);

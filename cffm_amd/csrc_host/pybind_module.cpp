@@ -44,6 +44,8 @@ PYBIND11_MODULE(_cffm_pybind, m) {
     CFFM_BIND(cffm_theta_layout);
     CFFM_BIND(cffm_ws_layout);
     CFFM_BIND(cffm_gather);
+    CFFM_BIND(cffm_gather_inner_fwd_ok);
+    CFFM_BIND(cffm_gather_inner_fwd);
     CFFM_BIND(cffm_inner_fwd);
     CFFM_BIND(cffm_inner_bwd);
     CFFM_BIND(cffm_outer_conv0_fwd);

@@ -28,6 +28,38 @@ import torch
 import torch.distributed as dist
 
 
+def sync_replicas(compute, group=None, tables=True, src=0):
+    """Make what must be identical on every rank identical: broadcast rank ``src``'s replicated state (dense parameters
+    and their optimizer slots; with ``tables`` also the three tables and their slots, which a data-parallel job
+    replicates).  ``compute.replicated_state(tables)`` yields the tensors; a compute without it is left alone (the
+    caller vouches for its replicas).  Gradients are only ever all-reduced, so replicas that start different stay
+    different for ever: both step classes call this at construction."""
+    state = getattr(compute, 'replicated_state', None)
+    if state is None:
+        return 0
+    n = 0
+    for t in state(tables):
+        dist.broadcast(t, src=src, group=group)
+        n += 1
+    return n
+
+
+def replicas_agree(compute, group=None, tables=False):
+    """True when a checksum of the replicated state (sum and sum of squares in float64) is bit-identical on every
+    rank: two all-reduces (MIN, MAX) of a few doubles."""
+    state = getattr(compute, 'replicated_state', None)
+    if state is None:
+        return True
+    ts = list(state(tables))
+    if not ts:
+        return True
+    chk = torch.stack([v for t in ts for v in (t.double().sum(), (t.double() * t.double()).sum())])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
 class DataParallelStep(object):
     """Two collectives per step.  The loss normaliser 1/L (CFFM.py:493) needs the loss-term sum over the GLOBAL
     batch; instead of a separate scalar all-reduce between forward and backward, the backward pass runs with
@@ -39,11 +71,14 @@ class DataParallelStep(object):
 
     Every rank applies the same update to its replica, so the replicas stay bit-identical."""
 
-    def __init__(self, compute, group=None, use_graph=False, mode='auto'):
+    def __init__(self, compute, group=None, use_graph=False, mode='auto', sync=True):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        if sync and self.world > 1:
+            # every variable is replicated in this mode: rank 0's parameters, tables and optimizer slots become everyone's
+            sync_replicas(compute, group, tables=True)
         self._gathered = {}
         # use_graph: the whole step (local kernels + the two RCCL collectives + the update) is captured once per batch
         # shape into a HIP graph and replayed, with the batch copied into fixed input buffers first.  Eager, one step
@@ -84,9 +119,16 @@ class DataParallelStep(object):
         key = (tuple(ids.shape), ids.dtype, y.dtype)
         st = self._graphs.get(key)
         if st is None:
-            st = {'ids': ids.clone(), 'y': y.clone(), 'calls': 0, 'graph': None, 'loss': None}
+            st = {'ids': ids.clone(), 'y': y.clone(), 'calls': 0, 'graph': None, 'loss': None, 'ws_gen': -1}
             self._graphs[key] = st
         st['calls'] += 1
+        gen = getattr(self.c, 'ws_generation', 0)
+        if st['graph'] is not None and st['ws_gen'] != gen:
+            # the engine re-allocated its workspace since the capture (a larger batch, evaluate()'s 8192-row blocks): the
+            # captured kernels still point at the old buffer, which the engine keeps alive while it is pinned.  Drop the
+            # graph and capture again against the current buffer.
+            st['graph'] = None
+            self._unpin()
         if st['graph'] is None:
             if st['calls'] <= 2:                 # warm-up: workspaces, communicators and kernel attributes get created eagerly
                 return self._eager(ids, y)
@@ -97,12 +139,20 @@ class DataParallelStep(object):
             with torch.cuda.graph(g):
                 st['loss'] = self._eager(st['ids'], st['y'])
             st['graph'] = g
+            st['ws_gen'] = getattr(self.c, 'ws_generation', 0)
+            if hasattr(self.c, 'pin_workspace'):
+                self.c.pin_workspace()           # from now on an outgrown workspace is retired, not freed
             g.replay()                           # capturing only records: run this batch now
             return st['loss']
         st['ids'].copy_(ids)
         st['y'].copy_(y)
         st['graph'].replay()
         return st['loss']
+
+    def _unpin(self):
+        if hasattr(self.c, 'unpin_workspace'):
+            torch.cuda.synchronize()             # no replay of the dropped graph is still running on the old buffer
+            self.c.unpin_workspace()
 
 
 def shard_of(ids, world):
@@ -187,7 +237,7 @@ class _Plan(object):
     """Routing of one batch through the row-sharded tables: everything the exchange needs that depends only on the ids.
     Built on the device without a host sync; the per-destination counts reach the host through an asynchronous copy into
     pinned memory and are only waited for when the step that uses them starts (one step later when prefetched)."""
-    __slots__ = ('ids', 'B', 'F', 'local_ids', 'order', 'uniq', 'pos', 'send_rows', 'counts_host', 'event', '_sc', '_rc')
+    __slots__ = ('ids', 'token', 'B', 'F', 'local_ids', 'order', 'uniq', 'pos', 'send_rows', 'counts_host', 'event', '_sc', '_rc')
 
     def counts(self):
         if self._sc is None:
@@ -196,6 +246,13 @@ class _Plan(object):
             c = self.counts_host.tolist()
             self._sc, self._rc = [int(v) for v in c[0]], [int(v) for v in c[1]]
         return self._sc, self._rc
+
+
+def batch_token(ids):
+    """What identifies the CONTENT of an id batch between the call that prefetched its plan and the call that uses it:
+    storage address, geometry and torch's version counter.  Indexing a tensor (``X[i]``) returns a fresh Python object
+    every time, so object identity would throw every prefetched plan away; an in-place write bumps ``_version``."""
+    return (ids.data_ptr(), tuple(ids.shape), tuple(ids.stride()), ids.dtype, ids._version)
 
 
 class ShardedStep(object):
@@ -217,13 +274,17 @@ class ShardedStep(object):
     never waits.  ``compute`` owns a LOCAL engine (cfg.M = local_rows_count): HipEngine in the product, the oracle in the
     CPU tests."""
 
-    def __init__(self, compute, group=None, dedup=True):
+    def __init__(self, compute, group=None, dedup=True, sync=True):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.dedup = dedup
         self._ahead = None
+        self.plans_built = self.plans_reused = 0      # how often a prefetched plan was consumed (tests, bench)
+        if sync and self.world > 1:
+            # only the dense parameters are replicated here (every rank owns its own rows of the tables)
+            sync_replicas(compute, group, tables=False)
 
     def _a2a(self, send, send_counts, recv_counts):
         recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
@@ -256,7 +317,8 @@ class ShardedStep(object):
         dist.all_to_all_single(recv_counts, counts, group=self.group)
         both = torch.stack([counts, recv_counts])
         p = _Plan()
-        p.ids, p.B, p.F = ids, B, F
+        self.plans_built += 1
+        p.ids, p.token, p.B, p.F = ids, batch_token(ids), B, F
         p.local_ids = local.to(torch.int32).reshape(B, F).contiguous()
         p.order, p.uniq, p.pos = order.to(torch.int32), uniq.to(torch.int32), pos.to(torch.int32)
         p.send_rows = send_rows.to(torch.int32)
@@ -273,8 +335,10 @@ class ShardedStep(object):
     def train_step(self, ids, y, next_ids=None):
         c = self.c
         plan, self._ahead = self._ahead, None
-        if plan is None or plan.ids is not ids:
+        if plan is None or plan.token != batch_token(ids):
             plan = self.plan(ids)
+        else:
+            self.plans_reused += 1
         if next_ids is not None:
             self._ahead = self.plan(next_ids)         # before this step's kernels: its counts are on the host long before needed
         B, Bg = plan.B, plan.B * self.world

@@ -29,7 +29,7 @@ def _ptr(t):
 
 
 class HipEngine(object):
-    def __init__(self, cfg, params=None, seed=2021, device='cuda:0'):
+    def __init__(self, cfg, params=None, seed=2021, device='cuda:0', table_seed=None):
         if not torch.cuda.is_available():
             raise RuntimeError('cffm_amd.HipEngine needs an MI355X (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -41,11 +41,16 @@ class HipEngine(object):
         self.tl = hip.theta_layout(self.shape)
         self._ws = {}
         self._ws_buf = None
+        self.ws_generation = 0                        # bumped whenever the workspace buffer is re-allocated
+        self._ws_pins = 0                             # captured graphs that reference the workspace (pin_workspace)
+        self._ws_retired = []                         # outgrown buffers such a graph may still replay against
         self._eval_scratch = None
         self._host_only = {}
         # params == 'device': the three tables are drawn ON the GPU with the reference's distributions (N(0, 0.1),
         # N(0, 0.01), exact zeros - CFFM.py:257-277); for vocabularies where a host-side draw + copy of M*(K+D) floats
-        # would dominate start-up (10 M features: 5 GB).  Dense parameters still come from init_params(seed).
+        # would dominate start-up (10 M features: 5 GB).  Dense parameters still come from init_params(seed); the device
+        # draw of the tables uses table_seed (default: seed).  Row-sharded ranks pass ONE seed for the replicated dense
+        # parameters and table_seed = seed + rank for their own shard of the tables.
         device_tables = isinstance(params, str) and params == 'device'
         if params is None or device_tables:
             params = init_params(cfg, seed=seed, tables=not device_tables)
@@ -82,9 +87,22 @@ class HipEngine(object):
         self._ta2 = C.addressof(self.tables_acc2) if self.tables_acc2 is not None else 0
         self.load_params(params)
         if device_tables:
-            gen = torch.Generator(device=dev).manual_seed(int(seed))
+            gen = torch.Generator(device=dev).manual_seed(int(seed if table_seed is None else table_seed))
             self.inner.normal_(0.0, 0.1, generator=gen)
             self.outer.normal_(0.0, 0.01, generator=gen)
+
+    def replicated_state(self, tables=True):
+        """Tensors that must be bit-identical on every rank of a multi-GPU job (cffm_amd.dist.sync_replicas): the dense
+        parameters and their optimizer slots; with ``tables`` (data-parallel mode) also the three tables and their slots.
+        In row-sharded mode the tables are per-rank shards and stay out."""
+        out = [self.theta, self.theta_acc]
+        if self.theta_acc2 is not None:
+            out.append(self.theta_acc2)
+        if tables:
+            out += [self.inner, self.outer, self.fbias, self.inner_acc, self.outer_acc, self.fbias_acc]
+            if self.theta_acc2 is not None:
+                out += [self.inner_acc2, self.outer_acc2, self.fbias_acc2]
+        return out
 
     # ---- named parameters <-> device buffers -------------------------------------------------------
     def _members(self):
@@ -196,9 +214,15 @@ class HipEngine(object):
     # ---- workspace ---------------------------------------------------------------------------------
     def workspace(self, B):
         """(buffer, layout) for a batch of B rows.  ONE buffer serves every batch size: the library recomputes the
-        layout from B on every call, so a buffer laid out for the largest B seen so far holds any smaller one (the
-        ragged last block of evaluate(), the varying row counts an owner receives in row-sharded mode).  It only ever
-        grows; at F32 D64 B8192 it is ~50 GB, so one copy per distinct B would exhaust HBM within a few steps."""
+        layout from B on every call, and a call only needs ``layout(B).bytes`` bytes from the start of the buffer, so
+        the buffer is re-allocated exactly when a layout asks for more bytes than it has (the byte count is NOT monotonic
+        in B - the slab plan of the backward changes with B - hence the check on bytes, never on B).  It only ever grows;
+        at F32 D64 B8192 it is ~50 GB, so one copy per distinct B would exhaust HBM within a few steps.
+
+        A captured HIP graph (DataParallelStep(use_graph=True)) has the buffer's address baked into its kernel arguments:
+        while ``pin_workspace()`` is in effect a buffer that is outgrown is RETIRED (kept alive), not freed, and
+        ``ws_generation`` changes so that the owner of the graph re-captures against the new buffer and then calls
+        ``release_retired()``."""
         B = int(B)
         wl = self._ws.get(B)
         if wl is None:
@@ -207,9 +231,31 @@ class HipEngine(object):
             wl = hip.ws_layout(self.shape, B)
             self._ws[B] = wl
         if self._ws_buf is None or self._ws_buf.numel() < int(wl.bytes):
-            self._ws_buf = None                           # release before allocating the larger one
+            if self._ws_buf is not None:
+                self.ws_generation += 1
+                if self._ws_pins > 0:
+                    self._ws_retired.append(self._ws_buf)      # a graph may still replay against it
+            self._ws_buf = None                           # release (unless retired) before allocating the larger one
             self._ws_buf = torch.empty(int(wl.bytes), dtype=torch.uint8, device=self.device)
         return self._ws_buf, wl
+
+    def reserve_workspace(self, B):
+        """Grow the workspace to what a batch of B rows needs (e.g. evaluate()'s 8192-row blocks) BEFORE a graph is
+        captured, so that no later call outgrows the captured buffer."""
+        return self.workspace(B)[0]
+
+    def pin_workspace(self):
+        """A graph that references the current workspace buffer exists from now on (see workspace())."""
+        self._ws_pins += 1
+
+    def unpin_workspace(self):
+        self._ws_pins = max(0, self._ws_pins - 1)
+        if self._ws_pins == 0:
+            self._ws_retired = []
+
+    def release_retired(self):
+        """Every graph that referenced a retired buffer has been dropped or re-captured."""
+        self._ws_retired = []
 
     def ws_tensor(self, B, member, shape, dtype=torch.float32, index=None):
         """View of one workspace intermediate (for the parity tests)."""
@@ -218,7 +264,7 @@ class HipEngine(object):
         if index is not None:
             off = off[index]
         n = int(np.prod(shape))
-        itemsize = 4
+        itemsize = torch.empty(0, dtype=dtype).element_size()
         return buf[int(off):int(off) + n * itemsize].view(dtype).reshape(shape)
 
     def _stream(self):
@@ -291,6 +337,18 @@ class HipEngine(object):
         buf, _ = self.workspace(B)
         hip.check(self.lib.cffm_forward(self._s, self._t, _ptr(self.theta), _ptr(ids),
                                         _ptr(y), B, _ptr(buf), self._stream()))
+
+    def gather_inner_fwd_ok(self):
+        """Wide shapes (F*(F-1)/2 > 64, K == D in {32, 64}, F <= 32): predict / train_step never materialise the rows."""
+        return bool(self.lib.cffm_gather_inner_fwd_ok(self._s))
+
+    def gather_inner_fwd(self, ids):
+        """cffm_gather_inner_fwd alone: the three lookups fused with the inner branch, the s0 pool and the first-order
+        inputs (ws.inner_out, ws.t1[:, :D], ws.fb, ws.sort_keys); the kernel the gather roofline is quoted on."""
+        ids = self._ids(ids)
+        B = ids.shape[0]
+        buf, _ = self.workspace(B)
+        hip.check(self.lib.cffm_gather_inner_fwd(self._s, self._t, _ptr(self.theta), _ptr(ids), B, _ptr(buf), self._stream()))
 
     def gather_packed(self, local_rows):
         """Owner side of a row-sharded lookup: int32 [m] local rows -> [m, K+D+4] packed records

@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
@@ -66,6 +66,8 @@ PROTOTYPES = {
     'cffm_theta_layout': (C.c_int, [_SH, _P]),
     'cffm_ws_layout': (C.c_int, [_SH, C.c_int32, _P]),
     'cffm_gather': (C.c_int, [_SH, _TB, _P, C.c_int32, _P, _P, _P, _P]),
+    'cffm_gather_inner_fwd_ok': (C.c_int, [_SH]),
+    'cffm_gather_inner_fwd': (C.c_int, [_SH, _TB, _P, _P, C.c_int32, _P, _P]),
     'cffm_inner_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
     'cffm_inner_bwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),
     'cffm_outer_conv0_fwd': (C.c_int, [_SH, _P, _P, C.c_int32, _P]),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 5
+#define CFFM_ABI_VERSION 6
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -120,6 +120,18 @@ int cffm_ws_layout(const cffm_shape_t *s, int32_t B, cffm_ws_layout_t *out);
  * fb [B,F].  Any of the three outputs may be NULL to skip that table. */
 int cffm_gather(const cffm_shape_t *s, const cffm_tables_t *t, const int32_t *ids, int32_t B,
                 float *Ei, float *Eo, float *fb, void *stream);
+
+/* The read-only form of the three lookups for WIDE shapes (F*(F-1)/2 > 64, K == D in {32, 64}, F <= 32: BASELINE configs[3]
+ * and [4]): tf.nn.embedding_lookup x3 (CFFM.py:303, :354, :422) fused with every consumer of a whole looked-up example - the
+ * inner branch (CFFM.py:304-343), the s0 sum pool of the outer-product map (CFFM.py:381) and the first-order inputs
+ * (CFFM.py:422): ids [B,F] -> ws.inner_out [B], ws.t1[:, 0:D] (s0), ws.fb [B,F], ws.sort_keys.  The rows go HBM -> LDS ->
+ * registers and are NOT written to ws.Ei / ws.Eo (cffm_predict / cffm_train_step / cffm_dp_local then fetch the rows again
+ * from the tables in the few later kernels that need them).  This is the kernel the HBM-gather roofline is quoted on.
+ * Returns CFFM_ERR_UNSUPPORTED for other shapes (cffm_gather_inner_fwd_ok(s) == 0): those run cffm_gather / the fused
+ * small-shape forward. */
+int cffm_gather_inner_fwd_ok(const cffm_shape_t *s);
+int cffm_gather_inner_fwd(const cffm_shape_t *s, const cffm_tables_t *t, const float *theta, const int32_t *ids, int32_t B,
+                          void *ws, void *stream);
 
 /* inner branch CFFM.py:304-343 on gathered rows: ws.Ei -> ws.inner_out */
 int cffm_inner_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);

@@ -28,14 +28,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cffm_abi_version() == hip.ABI_VERSION == 5
+    assert lib.cffm_abi_version() == hip.ABI_VERSION == 6
     assert b'bad shape' in lib.cffm_error_string(10001)
     # the pybind11 layer (north_star's binding) exposes the same entry points and is what the engine calls through
     fast = hip.fast()
     assert hip.binding_name() == 'pybind11', 'cffm_amd/lib/_cffm_pybind*.so is not built (make)'
     for name in declared:
         assert callable(getattr(fast, name)), name
-    assert fast.cffm_abi_version() == 5 and 'bad shape' in fast.cffm_error_string(10001)
+    assert fast.cffm_abi_version() == 6 and 'bad shape' in fast.cffm_error_string(10001)
     sh = hip.make_shape(CFFMConfig(M=10, F=3, K=8, D=8))
     assert fast.cffm_packed_row_floats(C.addressof(sh)) == lib.cffm_packed_row_floats(C.byref(sh)) == 20
     tl_a, tl_b = hip.ThetaLayout(), hip.ThetaLayout()
@@ -98,3 +98,29 @@ def test_engine_refuses_to_run_without_gpu():
     from cffm_amd.engine import HipEngine
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         HipEngine(CFFMConfig(M=10, F=3, K=8, D=8))
+
+
+def test_div_chunks_guard_boundary():
+    """The chunk -> (slot, piece) division of the packed gather / staging kernels (gather.hip: div_chunks), replayed in
+    numpy float64 at the host guard's boundary (total < 2^31): exact with the DOUBLE reciprocal the kernels now use;
+    the float reciprocal widened to double that they used before is off by more than the +-1 correction can repair."""
+    rng = np.random.default_rng(7)
+    for CH in (5, 9, 13, 17, 21, 25, 33, 129):
+        top = (1 << 31) - 1
+        g = np.unique(np.concatenate([np.arange(0, 4 * CH), top - np.arange(0, 4 * CH),
+                                      (top // CH - np.arange(0, 64)) * CH, (top // CH - np.arange(0, 64)) * CH - 1,
+                                      rng.integers(0, top, size=200000)]))
+        g = g[(g >= 0) & (g <= top)].astype(np.int64)
+        inv = np.float64(1.0) / np.float64(CH)
+        q = ((g.astype(np.float64) + 0.5) * inv).astype(np.int64)
+        r = g - q * CH
+        q = np.where(r < 0, q - 1, np.where(r >= CH, q + 1, q))
+        r = g - q * CH
+        assert np.array_equal(q, g // CH) and np.array_equal(r, g % CH), CH
+    # what round 2 shipped: 1.f / CH widened to double - wrong beyond the single correction near 2^30 for CH = 13
+    CH = 13
+    g = np.arange((1 << 30) - 5000, (1 << 30), dtype=np.int64)
+    inv32 = np.float64(np.float32(1.0) / np.float32(CH))
+    q = ((g.astype(np.float64) + 0.5) * inv32).astype(np.int64)
+    r = g - q * CH
+    assert np.any((r < -CH) | (r >= 2 * CH))

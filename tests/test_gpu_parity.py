@@ -83,6 +83,12 @@ CASES = {
     'f16-d32-b130': dict(M=3000, F=16, K=8, D=32, act='relu', B=130),
     'f20-d32-b300-selu': dict(M=5000, F=20, K=16, D=32, act='selu', B=300),
     'f32-d64-b160': dict(M=20000, F=32, K=64, D=64, act='relu', B=160, heavy=True),
+    # wide filters with K == D: predict / train_step take the non-materialising route (cffm_gather_inner_fwd: rows consumed in
+    # the kernel that fetches them, later kernels re-fetch from the tables) - the generic instances of that kernel at K = 32
+    # and K = 64, a ragged last phase (B % 4 != 0), a half-filled fetch wave (F = 13: 416 pieces) and B < 4
+    'f16-k32-d32-b70-selu': dict(M=3000, F=16, K=32, D=32, act='selu', B=70),
+    'f13-k64-d64-b9-prelu': dict(M=900, F=13, K=64, D=64, act='prelu', B=9),
+    'f20-k32-d32-b3-relu': dict(M=900, F=20, K=32, D=32, act='relu', B=3),
     # more than 4,096 lookups per step: the rocPRIM radix sort + segment walk of the sparse update (the CLI's default
     # --batch_size 1024), with heavy duplication (ids drawn from 150 values per column)
     'frappe-b1024-dups': dict(M=5382, F=10, K=32, D=32, act='selu', B=1024, id_range=150),
@@ -275,6 +281,39 @@ def test_forward_stages(name):
     close(eng.predict(ids).cpu().numpy(), out_ref, 'predict')
 
 
+WIDE_NM = ['f32-d64-relu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu']
+
+
+@pytest.mark.parametrize('name', WIDE_NM)
+def test_gather_inner_fwd_wide(name):
+    """cffm_gather_inner_fwd on its own: the three lookups fused with the inner branch, the s0 pool and the first-order inputs.
+    ws.Ei / ws.Eo must stay untouched (poisoned beforehand); fb is a copy (exact), inner_out and s0 against the oracle; then the
+    whole non-materialising forward (cffm_predict) with the workspace rows still poisoned."""
+    cfg, p32, X, y = make_case(name)
+    eng = engine_for(cfg, p32)
+    assert eng.gather_inner_fwd_ok()
+    B = X.shape[0]
+    out_ref, c = orc.forward(to64(p32), X, cfg)
+    ids = torch.from_numpy(X).cuda()
+    eng.workspace(B)
+    Ei, Eo = eng.ws_tensor(B, 'Ei', (B, cfg.F, cfg.K)), eng.ws_tensor(B, 'Eo', (B, cfg.F, cfg.D))
+    Ei.fill_(float('nan'))
+    Eo.fill_(float('nan'))
+    eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).fill_(float('nan'))
+    eng.gather_inner_fwd(ids)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(Ei).all()) and bool(torch.isnan(Eo).all())
+    np.testing.assert_array_equal(eng.ws_tensor(B, 'fb', (B, cfg.F)).cpu().numpy(), p32['feature_bias'][X][:, :, 0])
+    close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out (fused gather)')
+    close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy()[:, :cfg.D], c['t1'][:, :cfg.D], 's0 (fused gather)')
+    keys = eng.ws_tensor(B, 'sort_keys', (B * cfg.F,), dtype=torch.int64).cpu().numpy()
+    np.testing.assert_array_equal(keys >> 32, X.reshape(-1))
+    np.testing.assert_array_equal(keys & 0xffffffff, np.arange(B * cfg.F))
+    close(eng.predict(ids).cpu().numpy(), out_ref, 'predict (rows never materialised)')
+    assert bool(torch.isnan(Ei).all()) and bool(torch.isnan(Eo).all())
+    close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy(), c['t1'], 't1')
+
+
 @pytest.mark.parametrize('name', list(CASES))
 def test_backward_stages(name):
     cfg, p32, X, y = make_case(name)
@@ -336,7 +375,7 @@ TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-re
                'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
                'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
                'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu',
-               'f11-d32-b256-relu', 'f6-d64-b256-elu']
+               'f11-d32-b256-relu', 'f6-d64-b256-elu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu']
 
 
 @pytest.mark.parametrize('name,trained_like', [(n, t) for n in TRAIN_CASES for t in (True, False)] + [(n, True) for n in HEAVY])
@@ -472,7 +511,8 @@ def test_second_step_and_reproducibility():
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=None if k not in slack else slack[k].reshape(v.shape))
 
 
-@pytest.mark.parametrize('name', ['f33-d32-relu', 'f16-d32-b130', 'f20-d64-elu', 'frappe-b1024-dups', 'frappe-selu'])
+@pytest.mark.parametrize('name', ['f33-d32-relu', 'f16-d32-b130', 'f20-d64-elu', 'frappe-b1024-dups', 'frappe-selu',
+                                  'f16-k32-d32-b70-selu', 'f32-d64-relu'])
 def test_two_runs_bit_identical(name):
     """Every kernel family leaves the same bits on two runs of the same two steps: the direct layer-0 kernels (F >= 33,
     whose LDS float atomics only ever target the issuing wave's PRIVATE accumulator plane, so their order is the
