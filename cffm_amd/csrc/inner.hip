@@ -9,6 +9,8 @@
 
 #include "inner_body.hpp"
 
+#include <stdlib.h>
+
 __global__ __launch_bounds__(256) void inner_fwd_kernel(InnerFwdArgs ia) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     inner_fwd_body(ia, blockIdx.x, smem);
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     // first-order role (:422): the thread that fetches the FIRST piece of an inner row also fetches feature_bias of that id and
     // writes ws.fb / the sort key of the slot - with the id it already holds, so no dependent load sits in a phase
     const bool fo_on = fetch && is_in && cq == 0;
+    const bool wave_has_outer = (wave + 1) * 64 > F * K4 && wave * 64 < npiece;      // some lane of this wave fetches an outer piece
     int idn[E];                                                           // ids of the phase whose rows are fetched next
     auto load_ids = [&](int ph) {
 #pragma unroll
@@ -215,13 +218,15 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
                 }
             }
         }
+        if (wave_has_outer) {                                              // wave-uniform: the waves that hold only inner pieces skip
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (fetch) v = *reinterpret_cast<const f32x4*>(rows + buf * buf_bytes + e * slot_bytes + tid * 16);
-            float s = (v.x + v.y) + (v.z + v.w);
-            s = D4 == 16 ? row_group_sum<true>(s) : row_group_sum<false>(s);
-            if (fetch && !is_in && cq == 0) RS[(buf * E + e) * 32 + fq] = s;
+            for (int e = 0; e < E; ++e) {
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (fetch && !is_in) v = *reinterpret_cast<const f32x4*>(rows + buf * buf_bytes + e * slot_bytes + tid * 16);
+                float s = (v.x + v.y) + (v.z + v.w);
+                s = D4 == 16 ? row_group_sum<true>(s) : row_group_sum<false>(s);
+                if (fetch && !is_in && cq == 0) RS[(buf * E + e) * 32 + fq] = s;
+            }
         }
     };
 
@@ -246,36 +251,59 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
         f32x2 acc[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = (f32x2){0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < UPT; ++k) {
-            // two instructions per unit address pair: v_and_or_b32 and v_alignbit_b32 put the buffer bit on top of the 16-bit offsets
+        // The unit loop as a rolling pipeline over half steps (two examples each): while one half is computed, the LDS reads
+        // of the next one are in flight, so a wave's own reads hide behind its own arithmetic (with the four reads of a step
+        // issued and awaited together, 40 % of the SIMD cycles had no VALU instruction to issue: SQ_ACTIVE_INST_VALU,
+        // profiles/r03_gather_pmc.md).  The accumulators are pinned after every half step and nothing is scheduled across
+        // the pins: left alone, the compiler hoists the reads of ALL units to the top of the phase and sinks the arithmetic
+        // below them (267 spilled registers under the 128-register budget of a 1024-thread workgroup).
+        typedef const f32x2 __attribute__((address_space(3))) * lds2_t;
+        static_assert(E == 4, "two half steps of two examples");
+        f32x2 eiA[2], ejA[2], eiB[2], ejB[2];
+        auto issue = [&](int k, int half, f32x2* ei, f32x2* ej) {
+            // two instructions per address pair: v_and_or_b32 and v_alignbit_b32 put the buffer bit on top of the 16-bit offsets
             const uint32_t ai = (off[k] & 0xffffu) | ((uint32_t)par << 16);
             const uint32_t aj = __builtin_amdgcn_alignbit((uint32_t)par, off[k], 16);
-            typedef const f32x2 __attribute__((address_space(3))) * lds2_t;
-            f32x2 ei[E], ej[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                ei[e] = *(lds2_t)(size_t)(ai + e * slot_bytes);
-                ej[e] = *(lds2_t)(size_t)(aj + e * slot_bytes);
+            for (int e = 0; e < 2; ++e) {
+                ei[e] = *(lds2_t)(size_t)(ai + (2 * half + e) * slot_bytes);
+                ej[e] = *(lds2_t)(size_t)(aj + (2 * half + e) * slot_bytes);
             }
+        };
+        auto compute = [&](int k, int half, const f32x2* ei, const f32x2* ej) {
+            f32x2 x[2], z[2], c[2];
+            float mp[2];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                f32x2 x = ei[e] * ej[e];                                   // :310
-                x.x = act_f(x.x, act); x.y = act_f(x.y, act);              // :319
-                f32x2 z = __builtin_elementwise_fma((f32x2){x.x, x.x}, w0, cb2);      // :327  cw[tap*2+ch]
-                z = __builtin_elementwise_fma((f32x2){x.y, x.y}, w1, z);
-                const float mp = fmaxf(x.x, x.y);                          // :331
-                f32x2 c;
-                c.x = act_pos(fmaxf(z.x, 0.f), act); c.y = act_pos(fmaxf(z.y, 0.f), act);   // :478, :330
-                const f32x2 sv = c + (f32x2){mp, mp};                      // :332
-                acc[e] = __builtin_elementwise_fma(sv, w[k], acc[e]);      // :339
-            }
-            // keep the compiler from hoisting the LDS reads of ALL units to the top of the phase and sinking the arithmetic
-            // below them (it did: 267 spilled registers under the 128-register budget of a 1024-thread workgroup): the
-            // accumulators are pinned here, and nothing is scheduled across; the other three waves of the SIMD cover the
-            // LDS latency of this one
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
-            static_assert(E == 4, "the pin above names the four accumulators");
+            for (int e = 0; e < 2; ++e) x[e] = ei[e] * ej[e];                                   // :310
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { x[e].x = act_f(x[e].x, act); x[e].y = act_f(x[e].y, act); }   // :319
+#pragma unroll
+            for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].x, x[e].x}, w0, cb2);   // :327  cw[tap*2+ch]
+#pragma unroll
+            for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].y, x[e].y}, w1, z[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) mp[e] = fmaxf(x[e].x, x[e].y);                          // :331
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { c[e].x = act_pos(fmaxf(z[e].x, 0.f), act); c[e].y = act_pos(fmaxf(z[e].y, 0.f), act); }   // :478, :330
+#pragma unroll
+            for (int e = 0; e < 2; ++e) c[e] = c[e] + (f32x2){mp[e], mp[e]};                    // :332
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[2 * half + e] = __builtin_elementwise_fma(c[e], w[k], acc[2 * half + e]);   // :339
+        };
+        issue(0, 0, eiA, ejA);
+        issue(0, 1, eiB, ejB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            compute(k, 0, eiA, ejA);
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < UPT) issue(k + 1, 0, eiA, ejA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(k, 1, eiB, ejB);
+            asm volatile("" : "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < UPT) issue(k + 1, 1, eiB, ejB);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -283,27 +311,24 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
             const float v = wave_sum(acc[e].x + acc[e].y);
             if (lane == 0) red[(par * 16 + wave) * E + e] = v;
         }
-        // ---- s0 pool (:381): s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]).  All 1024 threads: (example, h, quarter
-        // of the i range); a thread starts from the suffix sum at the top of its quarter, the four quarters meet in a quad sum
-        {
-            const int e = tid >> 8, h = (tid >> 2) & 63, part = tid & 3;
-            const int b = ph * E + e;
+        // ---- s0 pool (:381): s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]): wavefront e takes example e, lane = h
+        // (the same order of operations as head_fwd_body).  Waves 0..3 sit on four different SIMDs.
+        if (wave < E) {
+            const int e = wave, h = lane, b = ph * E + e;
             const float* Eo = reinterpret_cast<const float*>(buf + e * slot_bytes) + F * K;
             const float* rs = RS + (par * E + e) * 32;
-            const int IP = (F - 1 + 3) >> 2;                               // i = 0 .. F-2 in four quarters
-            const int i_lo = part * IP, i_hi = min(i_lo + IP, F - 1) - 1;
-            float s = 0.f;
-            if (h < D && i_hi >= i_lo) {
-                float R = 0.f;
-                for (int j = F - 1; j > i_hi; --j) R += rs[j];
-                for (int i = i_hi; i >= i_lo; --i) {
-                    s += Eo[i * D + h] * R;
-                    R += rs[i];
-                }
+            const int hh = h < D ? h : 0;
+            float s = 0.f, R = 0.f;
+            int i = F - 2;
+            for (; i >= 7; i -= 8) {                                       // eight rows per step: their sixteen LDS reads are in flight together
+                float ev[8], rv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ev[u] = Eo[(i - u) * D + hh]; rv[u] = rs[i - u + 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { R += rv[u]; s += ev[u] * R; }
             }
-            s += dpp_mov<0xB1, 0xf>(s, 0.f);                               // quad_perm [1,0,3,2]
-            s += dpp_mov<0x4E, 0xf>(s, 0.f);                               // quad_perm [2,3,0,1]
-            if (part == 0 && h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
+            for (; i >= 0; --i) { R += rs[i + 1]; s += Eo[i * D + hh] * R; }
+            if (h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
         }
         if (more) row_sums(par ^ 1, nxt);                                  // waits for the rows that were in flight
         __syncthreads();

@@ -34,6 +34,25 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, float 
             if (MODE == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(s2));
             if (MODE == 4) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(s));
             if (MODE == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(t2));
+            if (MODE == 6) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[k]) : "v"(s));
+            if (MODE == 7) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(s), "v"(s2.y));
+            if (MODE == 8) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(s));
+            if (MODE == 9) asm volatile("v_max_f32 %0, 0, %0" : "+v"(a[k]));
+            if (MODE == 10) {   // the unit body of gather_inner_fwd_wide_kernel: 10 instructions
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(s2));
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(p[k].x));
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(p[k].y));
+                f32x2 z;
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(z) : "v"(p[k]), "v"(s2), "v"(t2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(z) : "v"(p[k]), "v"(t2));
+                float m;
+                asm volatile("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(p[k].x), "v"(p[k].y));
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(z.x));
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(z.y));
+                f32x2 mm = (f32x2){m, m};
+                asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(z) : "v"(mm));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[k]) : "v"(z), "v"(s2));
+            }
         }
     }
     float r = 0.f;
@@ -136,9 +155,11 @@ int main() {
     CK(hipMalloc(&sink, 1 << 20));
     // ---- A
     {
-        const int iters = 4096, blocks = 256 * 8;
-        const char* names[6] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_pk_mul_f32", "v_max_f32", "v_pk_add_f32"};
-        for (int m = 0; m < 6; ++m) {
+        const char* names[11] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_pk_mul_f32", "v_max_f32", "v_pk_add_f32", "v_max_i32",
+                                 "v_max3_f32", "v_add_f32", "v_max_f32 0,x", "unit body (10 instr)"};
+        for (int wps = 8; wps >= 2; wps >>= 1)
+        for (int m = 0; m < 11; ++m) {
+            const int iters = 4096, blocks = 256 * wps;
             float ms = time_ms(st, 5, [&](int) {
                 switch (m) {
                     case 0: hipLaunchKernelGGL(valu_kernel<0>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
@@ -146,15 +167,22 @@ int main() {
                     case 2: hipLaunchKernelGGL(valu_kernel<2>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
                     case 3: hipLaunchKernelGGL(valu_kernel<3>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
                     case 4: hipLaunchKernelGGL(valu_kernel<4>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
-                    default: hipLaunchKernelGGL(valu_kernel<5>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    case 5: hipLaunchKernelGGL(valu_kernel<5>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    case 6: hipLaunchKernelGGL(valu_kernel<6>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    case 7: hipLaunchKernelGGL(valu_kernel<7>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    case 8: hipLaunchKernelGGL(valu_kernel<8>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    case 9: hipLaunchKernelGGL(valu_kernel<9>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
+                    default: hipLaunchKernelGGL(valu_kernel<10>, dim3(blocks), dim3(256), 0, st, sink, iters, 1.0000001f); break;
                 }
             });
-            const double winstr = (double)blocks * 4 * iters * 8;   // wave-instructions
+            const double winstr = (double)blocks * 4 * iters * 8 * (m == 10 ? 10 : 1);   // wave-instructions
             const double lane_elems = (double)blocks * 256 * iters * 8 * ((m & 1) ? 2 : 1);
-            printf("VALU %-18s %8.3f ms  %7.2f T wave-lane-instr/s  %7.2f T element-ops/s\n", names[m], ms,
-                   winstr * 64 / (ms * 1e-3) / 1e12, lane_elems / (ms * 1e-3) / 1e12);
+            printf("VALU %d waves/SIMD %-22s %8.3f ms  %7.2f T wave-lane-instr/s  %6.2f ns per wave-instr per SIMD\n", wps, names[m], ms,
+                   winstr * 64 / (ms * 1e-3) / 1e12, ms * 1e6 / (winstr / 1024.0));
+            (void)lane_elems;
         }
     }
+    if (getenv("PROBE_VALU_ONLY")) return 0;
     // ---- B
     const int M = 1000000, F = 32, B = 8192, NSET = 8;
     const int n = B * F;
