@@ -262,6 +262,23 @@ def cpu_baseline(cfg, X, y, budget_s=9.0):
             'torch_cpu': round(torch_rate, 1), 'numpy_oracle': round(numpy_rate, 1)}
 
 
+def self_launch(n):
+    """Run this same command line under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous: the
+    container hostname may not resolve) and return its exit status.  Nothing here initialises the GPU."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -285,6 +302,11 @@ def main():
     ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as children (one process per GPU over RCCL), BEFORE
+        # this process touches the GPU - a process that has initialised HIP must never be replaced or forked into ranks.
+        # Rank 0 prints the JSON line on the inherited stdout; the exit status is the launcher's.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -318,12 +340,14 @@ def main():
         lcfg = copy.copy(cfg)
         lcfg.M = local_rows_count(cfg.M, rank, world)
         if on_device:
-            eng = HipEngine(lcfg, params='device', seed=2021 + rank, device=str(device))
+            # ONE seed for the replicated dense parameters, a per-rank seed for this rank's shard of the tables
+            eng = HipEngine(lcfg, params='device', seed=2021, table_seed=2021 + rank, device=str(device))
         else:
             eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=2021), rank, world), device=str(device))
         sh = ShardedStep(eng)
+        Xb, yb = [X[i] for i in range(n_pool)], [y[i] for i in range(n_pool)]
         # the routing plan of the next batch is issued one step ahead (its per-owner counts are on the host before needed)
-        step = lambda i: sh.train_step(X[i % n_pool], y[i % n_pool], next_ids=X[(i + 1) % n_pool])
+        step = lambda i: sh.train_step(Xb[i % n_pool], yb[i % n_pool], next_ids=Xb[(i + 1) % n_pool])
         barrier = lambda: dist.barrier()
     elif world > 1 or args.force_dp:
         from cffm_amd.dist import DataParallelStep
@@ -363,6 +387,12 @@ def main():
     loss = float(eng.loss_buf[0].item())
     if not np.isfinite(loss):
         raise SystemExit('bench.py: loss is not finite')
+    agree = None
+    if use_pg:                                           # every rank takes part: checksums of the replicated state, MIN == MAX
+        from cffm_amd.dist import replicas_agree
+        agree = replicas_agree(eng, tables=(args.tables != 'sharded'))
+        if not agree:
+            raise SystemExit('bench.py: the replicas diverged (rank %d)' % rank)
     if big:
         torch.cuda.empty_cache()
 
@@ -384,6 +414,12 @@ def main():
                              'frac': round(tf / (MFMA_F32_PEAK_TFLOPS * world), 4),
                              'note': 'conv0 runs factorised (rank-1 input channels), so executed FLOPs are lower'}
         res['binding'] = hip.binding_name()
+        if use_pg:
+            res['dist'] = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                           'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
+                           'replicas_bit_identical_after_run': agree}
+            if args.tables == 'sharded':
+                res['dist']['plans_built'], res['dist']['plans_reused'] = sh.plans_built, sh.plans_reused
         if world == 1 and not args.quick and args.tables == 'replicated' and not args.force_dp:
             # the same loop with the host-side batcher of CFFM.train in it (random start on the host, slice of the
             # device-resident split): SURVEY 8d's "second figure including host batching"

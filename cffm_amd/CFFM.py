@@ -125,21 +125,68 @@ class CFFM(object):
         self.engine = None
         self._packed = {}
         self.examples_per_sec = []
+        # multi-GPU (set by build_graph under torch.distributed): one process per GPU, data parallel over the batch
+        self.world, self.rank, self._dp = 1, 0, None
 
     # ---- engine / data residency -----------------------------------------------------------------------
     def build_graph(self):
         """Creates the device state (the reference builds the TF graph here, CFFM.py:531-541)."""
         import torch
-        from .engine import HipEngine
         # one process per GPU: the device is the launcher's LOCAL_RANK (torch.distributed.run) or the process's current
         # device; it is made current so that the library's launches and torch's stream agree on it
         dev = int(os.environ.get('LOCAL_RANK', torch.cuda.current_device() if torch.cuda.is_available() else 0))
         if torch.cuda.is_available():
             torch.cuda.set_device(dev)
-        self.engine = HipEngine(self.config, seed=self.random_seed, device='cuda:%d' % dev)
+        self.engine = self._make_engine(dev)
         if self.pretrain_flag > 0:
             self.load(self.save_file)
+        self._setup_dist()
         return self.engine
+
+    engine_factory = None          # tests plug a CPU stand-in (the oracle) in here; the product path is HipEngine
+
+    def _make_engine(self, dev):
+        if self.engine_factory is not None:
+            return type(self).engine_factory(self.config, self.random_seed)
+        from .engine import HipEngine
+        return HipEngine(self.config, seed=self.random_seed, device='cuda:%d' % dev)
+
+    def _setup_dist(self):
+        """One process per GPU under torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK in the environment), or a process
+        group the caller initialised: the train step becomes cffm_amd.dist.DataParallelStep - every rank its slice of the
+        SAME global batch, two collectives per step, replicas bit-identical (rank 0's parameters are broadcast at
+        construction) - and evaluate() splits the rows over the ranks and all-reduces the three metric sums.  The reference
+        is single-device (CFFM.py:19 pins one GPU), so this replaces nothing in it; at world size 1 nothing changes."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_available():
+            return
+        if not dist.is_initialized():
+            if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+                return
+            on_gpu = torch.cuda.is_available()
+            dist.init_process_group('nccl' if on_gpu else 'gloo',
+                                    device_id=self.engine.device if on_gpu else None)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if self.world == 1:
+            return
+        if os.environ.get('CFFM_TABLES', 'replicated') != 'replicated':
+            raise NotImplementedError('CFFM.train() runs replicated tables (DataParallelStep); row-sharded tables are driven '
+                                      'through cffm_amd.dist.ShardedStep (bench.py --tables sharded)')
+        if self.batch_size % self.world:
+            raise ValueError('--batch_size %d is not a multiple of the %d ranks' % (self.batch_size, self.world))
+        from .dist import DataParallelStep
+        self._dp = DataParallelStep(self.engine)
+
+    def _info(self, msg):
+        if self.rank == 0:
+            logging.info(msg)
+
+    def _all_reduce_sum(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
 
     def _device_split(self, data):
         """{'X': lists, 'Y': list} -> (ids int32 [N,F], y fp32 [N], (min label, max label)) in HBM, packed once per split
@@ -177,9 +224,9 @@ class CFFM(object):
             init_train_rmse, init_train_r2 = self.evaluate(data.Train_data)
             init_valid_rmse, init_validation_r2 = self.evaluate(data.Validation_data)
             init_test_rmse, init_test_r2 = self.evaluate(data.Test_data)
-            logging.info(("Init_RMSE: train=%.4f,validation=%.4f,test=%.4f | Init_R2: train=%.4f,validation=%.4f,"
-                          "test=%.4f [%.1f s] " % (init_train_rmse, init_valid_rmse, init_test_rmse, init_train_r2,
-                                                  init_validation_r2, init_test_r2, time() - t2)))
+            self._info(("Init_RMSE: train=%.4f,validation=%.4f,test=%.4f | Init_R2: train=%.4f,validation=%.4f,"
+                        "test=%.4f [%.1f s] " % (init_train_rmse, init_valid_rmse, init_test_rmse, init_train_r2,
+                                                init_validation_r2, init_test_r2, time() - t2)))
         ids, y, span = self._device_split(data.Train_data)
         n = ids.shape[0]
         # shuffle_in_unison_scary (CFFM.py:183, :556-558): sklearn's shuffle with the SAME random_state every epoch, i.e. one
@@ -194,10 +241,25 @@ class CFFM(object):
                 ids, y = ids[pt].contiguous(), y[pt].contiguous()
                 order = order[perm]
                 total_batch = int(n / self.batch_size)
-                for _ in range(total_batch):
-                    start = np.random.randint(0, n - self.batch_size)        # CFFM.py:561 (unseeded, as the reference)
-                    eng.train_step(ids[start:start + self.batch_size], y[start:start + self.batch_size])
-                torch.cuda.synchronize()
+                # CFFM.py:561: one unseeded np.random.randint per step.  Drawn for the whole epoch at once (the same stream
+                # as one call per step); under torch.distributed rank 0's draws are everyone's, so that the ranks cut
+                # their slices out of the SAME global batch.
+                starts = np.random.randint(0, n - self.batch_size, size=total_batch)
+                if self.world > 1:
+                    import torch.distributed as dist
+                    st = torch.from_numpy(starts.astype(np.int64)).to(ids.device)
+                    dist.broadcast(st, src=0)
+                    starts = st.cpu().numpy()
+                per = self.batch_size // self.world
+                for start in starts:
+                    start = int(start)
+                    if self._dp is not None:
+                        lo = start + self.rank * per
+                        self._dp.train_step(ids[lo:lo + per], y[lo:lo + per])
+                    else:
+                        eng.train_step(ids[start:start + self.batch_size], y[start:start + self.batch_size])
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 t2 = time()
                 self.examples_per_sec.append(total_batch * self.batch_size / max(t2 - t1, 1e-9))
                 self._packed[id(data.Train_data)] = (ids, y, self._token(data.Train_data), span)   # evaluate() sees the shuffled order
@@ -211,14 +273,15 @@ class CFFM(object):
                 self.valid_r2.append(valid_r2)
                 self.test_r2.append(test_r2)
                 if self.verbose > 0 and epoch % self.verbose == 0:
-                    logging.info(("Epoch %d [%.1f s] RMSE: train=%.4f,validation=%.4f,Test=%.4f | R2: train=%.4f,"
-                                  "validation=%.4f,Test=%.4f [%.1f s]" % (epoch + 1, t2 - t1, train_rmse, valid_rmse,
-                                                                          test_rmse, train_r2, valid_r2, test_r2,
-                                                                          time() - t2)))
-                    logging.info("Epoch %d throughput: %.0f training examples/s" % (epoch + 1, self.examples_per_sec[-1]))
+                    self._info(("Epoch %d [%.1f s] RMSE: train=%.4f,validation=%.4f,Test=%.4f | R2: train=%.4f,"
+                                "validation=%.4f,Test=%.4f [%.1f s]" % (epoch + 1, t2 - t1, train_rmse, valid_rmse,
+                                                                        test_rmse, train_r2, valid_r2, test_r2,
+                                                                        time() - t2)))
+                    self._info("Epoch %d throughput: %.0f training examples/s%s" % (
+                        epoch + 1, self.examples_per_sec[-1], ' (%d ranks)' % self.world if self.world > 1 else ''))
                 if self.eva_termination(self.valid_rmse):
                     break
-                if self.pretrain_flag < 0:
+                if self.pretrain_flag < 0 and self.rank == 0:        # the replicas are identical: rank 0 writes
                     logging.info("Save model to file as pretrain.")
                     self.save(self.save_file)
         finally:
@@ -242,7 +305,13 @@ class CFFM(object):
         num_example = int(ids.shape[0])
         if num_example == 0:
             raise ValueError('evaluate() needs at least one example')
-        sums = self.engine.eval_sums(ids, y, lo, hi, block=max(int(self.batch_size), 8192))
+        if self.world > 1:
+            # the forward is per example: every rank sweeps its contiguous share of the rows, the three sums are added up
+            share = -(-num_example // self.world)
+            r0, r1 = min(self.rank * share, num_example), min((self.rank + 1) * share, num_example)
+            sums = self._all_reduce_sum(self.engine.eval_sums(ids[r0:r1], y[r0:r1], lo, hi, block=max(int(self.batch_size), 8192)))
+        else:
+            sums = self.engine.eval_sums(ids, y, lo, hi, block=max(int(self.batch_size), 8192))
         ss_res, sy, syy = (float(v) for v in sums.cpu().numpy())
         if not math.isfinite(ss_res):
             # np.maximum/np.minimum propagate NaN and sklearn's mean_squared_error raises on it (CFFM.py:607-612): a
@@ -299,7 +368,7 @@ class CFFM(object):
     def calculate_parameters(self):
         total_parameters = logged_param_count(self.config)
         if self.verbose > 0:
-            logging.info("#params: %d" % total_parameters)
+            self._info("#params: %d" % total_parameters)
         return total_parameters
 
     def create_save_folder(self, save_file):

@@ -337,3 +337,165 @@ def test_route_ids_is_a_stable_grouping():
     assert ids[perm].tolist() == [9, 7, 4, 4, 1, 2, 8]       # stable inside each owner group
     o, l = shard_of(ids, 3)
     assert torch.equal(o * 1 + l * 3, ids)
+
+
+# ---- round 3: replicas built from DIFFERENT seeds, content-matched plan prefetch, the CFFM class over a process group --------
+def _state_tensors(comp, tables):
+    """replicated_state() of the oracle stand-ins: in-place torch views of the numpy parameters and accumulators."""
+    out = []
+    for d in (comp.p, comp.acc):
+        for k in sorted(d):
+            if not tables and k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
+                continue
+            if not (isinstance(d[k], np.ndarray) and d[k].flags['C_CONTIGUOUS'] and d[k].flags['WRITEABLE']):
+                d[k] = np.array(d[k], dtype=np.float64)
+            out.append(torch.from_numpy(d[k].reshape(-1)))
+    return out
+
+
+OracleCompute.replicated_state = lambda self, tables=True: _state_tensors(self, tables)
+
+
+def _per_rank_seed_worker(rank, world, sharded):
+    """Every rank draws its dense parameters from ITS OWN seed (what bench.py did for the device-drawn shards in round 2):
+    the step classes must broadcast rank 0's replicated state at construction, or the replicas never agree."""
+    from cffm_amd.dist import DataParallelStep, ShardedStep, local_rows_count, replicas_agree, shard_params
+    import copy
+    cfg, p0, X, y = _case()
+    p = init_params(cfg, seed=3 + 10 * rank, dtype=np.float64)           # rank 0: the seed of _case()
+    for k in ('feature_bias', 'outer_embeddings', 'inner_embeddings'):   # the tables as _case() prepares them (shared / sharded)
+        p[k] = p0[k].copy()
+    if sharded:
+        lcfg = copy.copy(cfg)
+        lcfg.M = local_rows_count(cfg.M, rank, world)
+        comp = ShardedOracleCompute(lcfg, shard_params(p, rank, world))
+        assert not replicas_agree(comp, tables=False)
+        step = ShardedStep(comp)
+    else:
+        p['inner_embeddings'] = p['inner_embeddings'] * (1.0 + rank)      # replicated tables that start different as well
+        comp = OracleCompute(cfg, p)
+        assert not replicas_agree(comp, tables=True)
+        step = DataParallelStep(comp)
+    assert replicas_agree(comp, tables=not sharded)
+    per = X.shape[0] // world
+    sl = slice(rank * per, rank * per + per)
+    X2 = (X[::-1] * 7 + 3) % cfg.M
+    l1 = step.train_step(torch.from_numpy(X[sl].copy()), torch.from_numpy(y[sl]))
+    l2 = step.train_step(torch.from_numpy(X2[sl].copy()), torch.from_numpy(y[sl]))
+    assert replicas_agree(comp, tables=not sharded)
+    return (float(l1[0]), float(l2[0])), {k: np.asarray(v).copy() for k, v in comp.p.items()}
+
+
+@pytest.mark.parametrize('sharded', [False, True])
+def test_replicas_built_from_per_rank_seeds_are_synchronised(sharded):
+    world = 2
+    res = _run(_per_rank_seed_worker, world, sharded)
+    cfg, p, X, y = _case()
+    X2 = (X[::-1] * 7 + 3) % cfg.M
+    acc = orc.init_accumulators(p)
+    L1, _ = orc.train_step(p, acc, X, y, cfg)
+    L2, _ = orc.train_step(p, acc, X2, y, cfg)
+    tables = ('inner_embeddings', 'outer_embeddings', 'feature_bias')
+    for rank in range(world):
+        (l1, l2), got = res[rank]
+        assert abs(l1 - L1) < 1e-12 and abs(l2 - L2) < 1e-10
+        for k, v in got.items():
+            ref = p[k][rank::world] if (sharded and k in tables) else p[k]
+            np.testing.assert_allclose(v, ref, rtol=1e-9, atol=1e-11, err_msg='rank %d %s' % (rank, k))
+    for k in res[0][1]:                                   # bit-identical replicas after two steps
+        if not (sharded and k in tables):
+            np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
+
+
+def _plan_token_worker(rank, world):
+    """bench.py hands ShardedStep X[i] / X[i + 1]: indexing a tensor builds a NEW Python object every time, so the
+    prefetched plan must be matched on content (storage, geometry, version), not on object identity."""
+    from cffm_amd.dist import ShardedStep, batch_token, local_rows_count, shard_params
+    import copy
+    cfg, p, X, y = _case()
+    lcfg = copy.copy(cfg)
+    lcfg.M = local_rows_count(cfg.M, rank, world)
+    step = ShardedStep(ShardedOracleCompute(lcfg, shard_params(p, rank, world)))
+    per = X.shape[0] // world
+    pool = torch.from_numpy(np.stack([X[rank * per:(rank + 1) * per], ((X[::-1] * 7 + 3) % cfg.M)[rank * per:(rank + 1) * per]]))
+    yt = torch.from_numpy(y[rank * per:(rank + 1) * per])
+    assert pool[1] is not pool[1] and batch_token(pool[1]) == batch_token(pool[1])
+    step.train_step(pool[0], yt, next_ids=pool[1])
+    step.train_step(pool[1], yt, next_ids=pool[0])           # fresh view objects of the same rows: the plan must be found
+    pool[0][0, 0] = (int(pool[0][0, 0]) + 1) % cfg.M         # an in-place write bumps the version: the stale plan is dropped
+    step.train_step(pool[0], yt)
+    return step.plans_built, step.plans_reused
+
+
+def test_prefetched_plan_is_matched_on_content_not_identity():
+    res = _run(_plan_token_worker, 2)
+    for rank in (0, 1):
+        built, reused = res[rank]
+        assert reused == 1 and built == 4, (built, reused)    # step 1: 2 plans; step 2: reuse + 1 ahead; step 3: stale -> 1 new
+
+
+class OracleEngine(OracleCompute):
+    """What cffm_amd.CFFM needs from an engine (HipEngine's surface), computed by the float64 oracle on CPU tensors."""
+    device = torch.device('cpu')
+    opt_step = 0
+
+    def __init__(self, cfg, seed):
+        OracleCompute.__init__(self, cfg, init_params(cfg, seed=seed, dtype=np.float64))
+
+    def train_step(self, ids, y):
+        L, _ = orc.train_step(self.p, self.acc, ids.numpy(), y.numpy().astype(np.float64), self.cfg)
+        return torch.tensor([L])
+
+    def eval_sums(self, ids, y, lo, hi, block=8192):
+        if ids.shape[0] == 0:
+            return torch.zeros(3, dtype=torch.float64)
+        out, _ = orc.forward(self.p, ids.numpy(), self.cfg)
+        yt = y.numpy().astype(np.float64)
+        pr = np.minimum(np.maximum(out, lo), hi)
+        return torch.tensor([np.sum((yt - pr) ** 2), yt.sum(), np.sum(yt * yt)], dtype=torch.float64)
+
+    def export_params(self):
+        return {k: np.asarray(v).copy() for k, v in self.p.items()}
+
+
+def _cffm_class_worker(rank, world, tmp):
+    """The drop-in class under a process group: CFFM.train() runs DataParallelStep on every rank's slice of the SAME global
+    batches (rank 0's random starts are broadcast), evaluate() splits the rows and all-reduces the metric sums."""
+    from cffm_amd import CFFM as M
+    from cffm_amd import synth
+
+    class Split(dict):
+        pass
+
+    rng = np.random.default_rng(11)
+    Mf, F = 40, 4
+
+    def split(n):
+        return Split(X=synth.sample_ids(rng, Mf, F, n).tolist(), Y=synth.sample_labels(rng, n).tolist())
+
+    class Data(object):
+        pass
+    data = Data()
+    data.Train_data, data.Validation_data, data.Test_data = split(37), split(11), split(9)
+    M.CFFM.engine_factory = OracleEngine
+    try:
+        m = M.CFFM(Mf, 0, os.path.join(tmp, 'r%d_w%d' % (rank, world)), 8, 8, 'square_loss', 2, 8, 0.05, 0, [1.0, 1.0],
+                   'AdagradOptimizer', 0, 0, 0, F, 1, 0, 1.0, 1, 1.0, 1, 1.0, 'relu')
+        np.random.seed(77)                                   # the reference's batch starts are unseeded: pin them for the test
+        m.train(data)
+    finally:
+        M.CFFM.engine_factory = None
+    assert m.world == world and (m._dp is not None) == (world > 1)
+    return (m.train_rmse, m.valid_rmse, m.test_rmse, m.train_r2), m.engine.export_params()
+
+
+def test_cffm_class_trains_data_parallel_under_a_process_group(tmp_path):
+    one = _run(_cffm_class_worker, 1, str(tmp_path))[0]
+    two = _run(_cffm_class_worker, 2, str(tmp_path))
+    for rank in (0, 1):
+        for a, b in zip(one[0], two[rank][0]):              # per-epoch metrics: identical on every rank, equal to the single run
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+        for k, v in one[1].items():
+            np.testing.assert_allclose(two[rank][1][k], v, rtol=1e-8, atol=1e-11, err_msg='rank %d %s' % (rank, k))
+    for k in two[0][1]:
+        np.testing.assert_array_equal(two[0][1][k], two[1][1][k], err_msg=k)
