@@ -302,10 +302,11 @@ def main():
     ap.add_argument('--quick', action='store_true', help='skip stage times, roofline, peaks and the CPU baseline')
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or os.environ.get('CFFM_BENCH_SELF_LAUNCH')) and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as children (one process per GPU over RCCL), BEFORE
         # this process touches the GPU - a process that has initialised HIP must never be replaced or forked into ranks.
-        # Rank 0 prints the JSON line on the inherited stdout; the exit status is the launcher's.
+        # Rank 0 prints the JSON line on the inherited stdout; the exit status is the launcher's.  (CFFM_BENCH_SELF_LAUNCH=1
+        # takes the same route at N = 1: how the route is checked on a one-GPU box.)
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -313,3 +313,39 @@ def test_sharded_checkpoint_round_trip(tmp_path):
                 np.testing.assert_array_equal((a if k in tables else a0)[k], b[k], err_msg='rank %d %s %s' % (r, exp, k))
     with pytest.raises(ValueError):
         load_sharded(engines[0][1], path, 1, G) if engines[0][0].M != engines[1][0].M else (_ for _ in ()).throw(ValueError('same size'))
+
+
+def test_graph_replay_survives_a_workspace_regrowth(nccl_world1):
+    """DataParallelStep(use_graph=True) bakes the workspace address into its captured kernels.  A later, larger request
+    (evaluate()'s 8192-row blocks) re-allocates the workspace: the engine must keep the outgrown buffer alive while a graph
+    is pinned to it, and the step must re-capture against the new one - an eager twin that never used a graph stays
+    bit-identical through the whole sequence."""
+    from cffm_amd.dist import DataParallelStep
+    from cffm_amd.engine import HipEngine
+    from tests.test_gpu_parity import make_case
+    cfg, p32, X, y = make_case('bookx-relu')
+    rng = np.random.default_rng(9)
+    batches = [rng.integers(0, cfg.M, size=X.shape).astype(np.int32) for _ in range(7)]
+    big = torch.from_numpy(rng.integers(0, cfg.M, size=(8192, cfg.F)).astype(np.int32)).cuda()
+    yt = torch.from_numpy(y).cuda()
+    eng_g, eng_e = HipEngine(cfg, params=p32), HipEngine(cfg, params=p32)
+    dp_g, dp_e = DataParallelStep(eng_g, use_graph=True), DataParallelStep(eng_e, use_graph=False)
+    for i, Xb in enumerate(batches):
+        ids = torch.from_numpy(Xb).cuda()
+        lg, le = dp_g.train_step(ids, yt), dp_e.train_step(ids, yt)
+        torch.cuda.synchronize()
+        assert float(lg) == float(le), i
+        if i == 3:                                    # a graph exists by now (captured at the third call)
+            st = next(iter(dp_g._graphs.values()))
+            assert st['graph'] is not None and eng_g._ws_pins == 1
+            gen = eng_g.ws_generation
+            old = eng_g._ws_buf
+            pg, pe = eng_g.predict(big), eng_e.predict(big)          # outgrows the captured workspace
+            torch.cuda.synchronize()
+            assert eng_g.ws_generation == gen + 1 and eng_g._ws_retired and eng_g._ws_retired[0] is old
+            assert torch.equal(pg, pe)
+    st = next(iter(dp_g._graphs.values()))
+    assert st['graph'] is not None and st['ws_gen'] == eng_g.ws_generation      # re-captured against the new buffer
+    a, b = eng_g.export_params(), eng_e.export_params()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

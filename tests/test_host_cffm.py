@@ -156,3 +156,29 @@ def test_train_leaves_the_callers_lists_shuffled_like_the_reference(tmp_path):
     # and the device copy follows the same order: evaluate() on the re-bound lists does not re-pack
     ids, y, _ = m._device_split(data.Train_data)
     assert ids.cpu().numpy().tolist() == Xr
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment launches N ranks as CHILD processes through
+    torch.distributed.run on 127.0.0.1 and hands their status back; nothing in that route may touch the GPU."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '5', '--warmup', '2'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    import torch
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: (_ for _ in ()).throw(AssertionError('GPU touched before the launch')))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '5', '--warmup', '2']
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
