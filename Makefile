@@ -36,6 +36,19 @@ $(OUT)/libcffm_hip.so: $(OBJS)
 	@mkdir -p $(OUT)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
+# CPU sanitizer build of the two host shims (libfm reader, pybind11 layer) and the loader / ABI tests run against it.
+# CPU only: GPU AddressSanitizer is not available on the MI355X pool.
+ASAN_DIR := build/asan
+ASAN_FLAGS := -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
+asan: $(OUT)/libcffm_hip.so
+	@mkdir -p $(ASAN_DIR)
+	g++ $(ASAN_FLAGS) -Wall cffm_amd/csrc_host/libfm_reader.cpp -o $(ASAN_DIR)/libcffm_libfm.so
+	g++ $(ASAN_FLAGS) -fvisibility=hidden $(shell python3 -m pybind11 --includes) cffm_amd/csrc_host/pybind_module.cpp \
+	  -o $(ASAN_DIR)/_cffm_pybind$(shell python3-config --extension-suffix) -L$(OUT) -lcffm_hip -Wl,-rpath,'$(abspath $(OUT))'
+	LD_PRELOAD="$(shell gcc -print-file-name=libasan.so) $(shell gcc -print-file-name=libubsan.so)" \
+	  ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+	  CFFM_HOST_LIB_DIR=$(abspath $(ASAN_DIR)) python3 -m pytest tests/test_loader.py tests/test_abi.py -x -q -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -rf build $(OUT)/libcffm_hip.so $(OUT)/libcffm_libfm.so $(PYEXT)
-.PHONY: all clean
+.PHONY: all clean asan

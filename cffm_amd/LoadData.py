@@ -28,7 +28,9 @@ import os
 
 import numpy as np
 
-_NATIVE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libcffm_libfm.so')
+# CFFM_HOST_LIB_DIR: another build of the two host shims (the sanitizer build of `make asan`)
+_NATIVE_PATH = os.path.join(os.environ.get('CFFM_HOST_LIB_DIR') or
+                            os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib'), 'libcffm_libfm.so')
 _native = None
 
 

@@ -3480,6 +3480,19 @@ int cffm_conv01_bwd_impl(const cffm_shape_t* s, const float* theta, void* ws, in
     if (sp.r[sp.conv0].nslab != 256 || sp.r[sp.conv0 + 1].nslab != 256 || a.n2 > 256 || a.n3 > 256 ||
         (int64_t)a.n2 * CFFM_TOP_SLAB_ROWS < a.w2.Mtot || (int64_t)a.n3 * CFFM_TOP_SLAB_ROWS < a.w3.Mtot)
         return CFFM_ERR_UNSUPPORTED;             // one layer-0/1 slab per workgroup, the 64-row slabs cover layers 2 and 3
+    // Host-side guard (round-2 review, weak #6): the argument block starts zero-filled, and a role that dereferenced a member
+    // nobody assigned would fault the GPU at address 0.  Every pointer ANY group of the kernel can dereference is checked here,
+    // together with the row counts its clamped addresses are derived from (m = Mtot - 1 for rows past the end).
+    {
+        const void* must[] = {a.d0.dC, a.d0.W, a.d0.Cprev, a.d0.dt1, a.d0.dprev, a.slabW0, a.slabB0, a.d1.dC, a.d1.W, a.d1.Cprev,
+                              a.d1.dt1, a.d1.dprev, a.w1.in, a.w1.dC, a.w1.slabW, a.w1.slabB, a.w2.in, a.w2.dC, a.w2.slabW,
+                              a.w2.slabB, a.w3.in, a.w3.dC, a.w3.slabW, a.w3.slabB};
+        for (const void* q : must)
+            if (q == nullptr) return CFFM_ERR_BAD_SHAPE;
+        if (a.d0.Mtot <= 0 || a.d1.Mtot <= 0 || a.w1.Mtot <= 0 || a.w2.Mtot <= 0 || a.w3.Mtot <= 0 || a.n2 < 1 || a.n3 < 1 ||
+            a.stride0 <= 0 || a.w1.slab_stride <= 0 || a.w2.slab_stride <= 0 || a.w3.slab_stride <= 0)
+            return CFFM_ERR_BAD_SHAPE;
+    }
     const int NW = 16, PP = g.Pp;
     const size_t lds = conv0_fact_bwd_lds(PP, g.F, g.D);       // the layer-0 phases; the weight gradients need 3 x 64*PP*4
 #define CFFM_C01_LAUNCH(NTV, FV, DV, ACTV)                                                                       \

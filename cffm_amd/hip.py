@@ -136,7 +136,15 @@ def fast():
     if _fast is None:
         lib = load()                                   # libcffm_hip.so (and through torch, libamdhip64) is in the process
         try:
-            from .lib import _cffm_pybind as mod
+            alt = os.environ.get('CFFM_HOST_LIB_DIR')          # another build of the host shims (`make asan`)
+            if alt:
+                import glob
+                import importlib.util
+                spec = importlib.util.spec_from_file_location('_cffm_pybind', glob.glob(os.path.join(alt, '_cffm_pybind*.so'))[0])
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+            else:
+                from .lib import _cffm_pybind as mod
             if mod.cffm_abi_version() != ABI_VERSION:
                 raise ImportError('stale _cffm_pybind')
             missing = [n for n in PROTOTYPES if not hasattr(mod, n)]

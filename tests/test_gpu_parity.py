@@ -69,6 +69,10 @@ CASES = {
     'mltag-elu': dict(M=2000, F=3, K=32, D=32, act='elu', B=64),
     'bookx-relu': dict(M=3000, F=6, K=32, D=32, act='relu', B=48),
     'frappe-selu': dict(M=5382, F=10, K=32, D=32, act='selu', B=256),
+    # the other two README commands at their OWN batch size and vocabulary (README.md:20, :24 - BASELINE configs[0] and [2]):
+    # every forward / backward stage and the full train step, not only forward rows
+    'mltag-full': dict(M=90445, F=3, K=32, D=32, act='elu', B=1024),
+    'bookx-full': dict(M=226336, F=6, K=32, D=32, act='relu', B=512),
     'f32-d64-relu': dict(M=4000, F=32, K=64, D=64, act='relu', B=3),
     'f12-d32-nolinatt': dict(M=500, F=12, K=16, D=32, act='selu', B=20, linear_att=0),
     # batch-size edges of the one-workgroup-per-example kernels: a single example, and B > 256 (workgroup 0 takes two)
@@ -371,7 +375,7 @@ def test_backward_stages(name):
             assert np.all(v == 0), k
 
 
-TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
+TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'mltag-full', 'bookx-full', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
                'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
                'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
                'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu',
@@ -384,6 +388,12 @@ def test_train_step_matches_oracle(name, trained_like):
     variable, including the sparse (duplicates-summed-first) table updates."""
     cfg, p32, X, y = make_case(name, trained_like=trained_like)
     eng = engine_for(cfg, p32)
+    step_check(cfg, eng, p32, None, X, y, name)
+
+
+def step_check(cfg, eng, p32, acc0, X, y, name):
+    """One train step of `eng` (whose state is p32 / acc0; acc0 = None: the initial accumulators) against one oracle step from
+    the same state: loss, post-update parameters and accumulators within the gradient tolerance propagated through Adagrad."""
     p64 = to64(p32)
     B = X.shape[0]
     eng.forward(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())   # same forward the step will redo
@@ -421,6 +431,10 @@ def test_train_step_matches_oracle(name, trained_like):
                 np.add.at(dgs[tname], ids_flat, slack[key].reshape(ids_flat.shape[0], -1))
     del cache
     acc = orc.init_accumulators(p64)
+    if acc0 is not None:
+        for k, v in acc0.items():
+            acc[k] = np.asarray(v, dtype=np.float64).reshape(np.shape(acc[k])).copy()
+    acc_before = {k: np.array(v) for k, v in acc.items()}
     p_before = {k: np.array(v) for k, v in p64.items()}
     for k, gk in grads.items():             # Adagrad (CFFM.py:523-524) from the gradients above: same as orc.train_step
         if k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
@@ -431,7 +445,7 @@ def test_train_step_matches_oracle(name, trained_like):
     for tname, key in (('inner_embeddings', 'd_inner_rows'), ('outer_embeddings', 'd_outer_rows'), ('feature_bias', 'd_bias_rows')):
         if key in g:
             orc.adagrad_sparse(p64[tname], acc[tname], ids_flat, g[key], cfg.lr)
-    if name == 'tiny-relu':                 # the hand-rolled update above IS orc.train_step (checked once, cheap case)
+    if name == 'tiny-relu' and acc0 is None:    # the hand-rolled update above IS orc.train_step (checked once, cheap case)
         q = {k: np.array(v) for k, v in p_before.items()}
         qa = orc.init_accumulators(q)
         orc.train_step(q, qa, X, y.astype(np.float64), cfg, cache_hook=hook)
@@ -450,7 +464,8 @@ def test_train_step_matches_oracle(name, trained_like):
         if k in grads:
             gk = grads[k].reshape(v.shape)
             dg = dgs[k].reshape(v.shape)
-            u = lambda t: cfg.lr * t / np.sqrt(1e-8 + t * t)          # monotonic: the worst case sits at g +- dg
+            a0 = acc_before[k].reshape(v.shape)                       # 1e-8 at the first step (CFFM.py:524)
+            u = lambda t: cfg.lr * t / np.sqrt(a0 + t * t)            # monotonic: the worst case sits at g +- dg
             extra = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
             acc_extra = 2 * np.abs(gk) * dg + dg * dg
         close(v, p64[k].reshape(v.shape), 'param ' + k, tol=2e-5, extra=extra)
@@ -461,7 +476,7 @@ def test_train_step_matches_oracle(name, trained_like):
     touched[X.reshape(-1)] = True
     for k in ('inner_embeddings', 'outer_embeddings', 'feature_bias'):
         np.testing.assert_array_equal(got[k][~touched], p32[k][~touched])
-        assert np.all(gacc[k][~touched] == np.float32(1e-8))
+        np.testing.assert_array_equal(gacc[k][~touched], acc_before[k].reshape(gacc[k].shape)[~touched].astype(np.float32))
     # a disabled branch leaves its table and every parameter of its own exactly as they were
     if not cfg.inner_conv:
         np.testing.assert_array_equal(got['inner_embeddings'], p32['inner_embeddings'])
@@ -482,6 +497,37 @@ def adagrad_step_slack(grads, acc_prev, lr, rel=1e-5):
         u = lambda t: lr * t / np.sqrt(a + t * t)
         out[k] = np.maximum(np.abs(u(gk + dg) - u(gk)), np.abs(u(gk - dg) - u(gk)))
     return out
+
+
+def test_frappe_trajectory_of_30_steps_follows_the_oracle():
+    """The reference runs thousands of steps (CFFM.py:186-200); this follows 30 of them at the headline shape (frappe command,
+    batch 256, selu, Adagrad 0.05) on 30 synthetic batches.
+
+    Adagrad with initial_accumulator_value = 1e-8 moves a parameter by ~lr * sign(g) at its first touch, so wherever a gradient
+    element is within rounding of 0 the step is decided by the last bit: two free-running trajectories (fp32 device, fp64
+    oracle) are 1e-4 apart in the loss after 3 steps and 1.4 % after 5 (measured) - as any two fp32 implementations would
+    be.  What CAN be pinned, and is: at EVERY one of the 30 states the device visits, one oracle step from that same state
+    (parameters and accumulators read back) agrees with the device step in loss, post-update parameters and accumulators
+    within the single-step bounds of step_check(); and the free-running oracle descends like the device does."""
+    from cffm_amd import synth
+    cfg = CFFMConfig(M=5382, F=10, K=32, D=32, activation='selu', lr=0.05, lamda_att=1.0)
+    Xs, ys = synth.batches(cfg.M, cfg.F, 256, 30, seed=11)
+    p32 = init_params(cfg, seed=2021, dtype=np.float32)
+    eng = engine_for(cfg, p32)
+    free = to64(p32)
+    free_acc = orc.init_accumulators(free)
+    dev_losses, free_losses = [], []
+    host_only = {k: v for k, v in p32.items()}
+    for i in range(30):
+        state = dict(host_only)
+        state.update(eng.export_params())
+        accs = eng.export_accumulators() if i else None
+        step_check(cfg, eng, state, accs, Xs[i], ys[i], 'trajectory')        # runs eng.train_step on batch i
+        dev_losses.append(float(eng.loss_buf.cpu()[0]))
+        free_losses.append(float(orc.train_step(free, free_acc, Xs[i], ys[i].astype(np.float64), cfg)[0]))
+    print('device loss   : ' + ' '.join('%.3f' % v for v in dev_losses))
+    print('free fp64 loss: ' + ' '.join('%.3f' % v for v in free_losses))
+    assert dev_losses[-1] < 0.2 * dev_losses[0] and abs(np.mean(dev_losses[-5:]) - np.mean(free_losses[-5:])) < 0.25 * np.mean(free_losses[-5:])
 
 
 def test_second_step_and_reproducibility():

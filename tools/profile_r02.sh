@@ -5,7 +5,7 @@
 tag=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-run() { out=$1; shift; rocprofv3 "$@" > $R/gpurun_out/$out.log 2>&1; echo "$out rc=$?"; }
+run() { out=$1; shift; timeout -k 10 ${CFFM_PROF_TIMEOUT:-600} rocprofv3 "$@" > $R/gpurun_out/$out.log 2>&1; echo "$out rc=$?"; }
 # 1) kernel trace, frappe (contract workload) and the stress shape
 run ${tag}_kt_frappe --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_kt_frappe -- python3 $R/bench.py --steps 50 --warmup 5 --blocks 1 --no-cpu-baseline
 run ${tag}_kt_syn1m --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_kt_syn1m -- python3 $R/bench.py --workload syn1m --steps 3 --warmup 1 --quick
