@@ -294,9 +294,9 @@ extern "C" int cffm_dp_local_dense(const cffm_shape_t* s, const cffm_tables_t* t
     if (!y || s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2 || !cffm_fwd_all_ok(s, B)) return CFFM_ERR_UNSUPPORTED;
     cffm_theta_layout_t tl;
     cffm_theta_layout(s, &tl);
-    const int64_t toff = ((int64_t)tl.n + 4 + 3) / 4 * 4;
-    hipError_t e = hipMemsetAsync(flat + tl.n, 0, (size_t)(toff - tl.n + (int64_t)s->M * (s->K + s->D + 1)) * 4, st);
-    if (e != hipSuccess) return (int)e;
+    // The table image of `flat` must be all zeros on entry: cffm_dp_apply_dense leaves it that way (zero on exit), so only
+    // the very first step needs a cleared buffer (the round-2 code paid a hipMemsetAsync of the 1.4 MB image, 4.5 us in front of
+    // the forward launch, on every step).
     const bool later = defer_rank(s, B);
     if ((rc = cffm_fwd_all_impl(s, tab, theta, ids, y, B, ws, st, !later))) return rc;
     if ((rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, flat, false, nullptr, st, true, true,

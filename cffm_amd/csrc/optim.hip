@@ -620,7 +620,7 @@ int cffm_dp_tail_dense(const cffm_shape_t* s, int32_t B, void* ws, float* flat, 
     return 0;
 }
 
-struct DenseTableArgs { float *w[3], *a[3]; const float* g[3]; int64_t n[3]; };
+struct DenseTableArgs { float *w[3], *a[3]; float* g[3]; int64_t n[3]; };
 __global__ __launch_bounds__(256) void dp_apply_dense_kernel(float* __restrict__ v, float* __restrict__ acc, const float* __restrict__ grad,
                                                              int64_t n, float lr, LateScale ls, float* __restrict__ loss_out, int n_dense,
                                                              DenseTableArgs t) {
@@ -631,6 +631,7 @@ __global__ __launch_bounds__(256) void dp_apply_dense_kernel(float* __restrict__
     for (int k = 0; k < 3; ++k) {
         if (i < t.n[k]) {
             const float g = t.g[k][i] * gs;
+            t.g[k][i] = 0.f;                                 // zero on exit: the next step's scatter finds a clean image (no memset)
             const float a = t.a[k][i] + g * g;               // g == 0 (row not looked up by any rank): a and w unchanged
             t.a[k][i] = a;
             t.w[k][i] -= lr * g / sqrtf(a);
@@ -648,7 +649,7 @@ extern "C" int64_t cffm_dp_dense_floats(const cffm_shape_t* s) {
 }
 
 extern "C" int cffm_dp_apply_dense(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_tables_t* acc, float* theta,
-                                   float* theta_acc, const float* flat_sum, int64_t B_global, float* loss_out, void* stream) {
+                                   float* theta_acc, float* flat_sum, int64_t B_global, float* loss_out, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (!s->inner_conv || !s->outer_conv) return CFFM_ERR_UNSUPPORTED;

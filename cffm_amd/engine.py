@@ -45,6 +45,7 @@ class HipEngine(object):
         self._ws_pins = 0                             # captured graphs that reference the workspace (pin_workspace)
         self._ws_retired = []                         # outgrown buffers such a graph may still replay against
         self._eval_scratch = None
+        self._flat_dirty = False                      # dense-image route: the image is zero on entry, zero on exit
         self._host_only = {}
         # params == 'device': the three tables are drawn ON the GPU with the reference's distributions (N(0, 0.1),
         # N(0, 0.01), exact zeros - CFFM.py:257-277); for vocabularies where a host-side draw + copy of M*(K+D) floats
@@ -475,6 +476,9 @@ class HipEngine(object):
         if flat is None:
             flat = torch.zeros(int(self.lib.cffm_dp_dense_floats(self._s)), dtype=torch.float32, device=self.device)
             self._ws['flat'] = flat
+        elif self._flat_dirty:
+            flat.zero_()                     # a step was abandoned between the two halves: the image contract is zero on entry
+        self._flat_dirty = True
         hip.check(self.lib.cffm_dp_local_dense(self._s, self._t, _ptr(self.theta), _ptr(ids), _ptr(y),
                                                int(B), int(B_global), _ptr(buf), _ptr(flat), self._stream()))
         return flat
@@ -483,6 +487,9 @@ class HipEngine(object):
         hip.check(self.lib.cffm_dp_apply_dense(self._s, self._t, self._ta,
                                                _ptr(self.theta), _ptr(self.theta_acc), _ptr(flat_sum), int(B_global),
                                                _ptr(self.loss_buf), self._stream()))
+        own = self._ws.get('flat')
+        if own is not None and flat_sum.data_ptr() == own.data_ptr():
+            self._flat_dirty = False         # cffm_dp_apply_dense cleared the image it consumed (zero on exit)
         return self.loss_buf
 
     def apply_dense(self):

@@ -193,12 +193,15 @@ int cffm_dp_local(const cffm_shape_t *s, const cffm_tables_t *tab, const float *
  * leaves ONE buffer flat = [theta.n gradients | loss sum | pad | duplicates-summed table gradients as a dense
  * [M][K | D | 1] image] of cffm_dp_dense_floats(s) floats; the caller all-reduces (sums) it over the ranks and every
  * rank applies it with cffm_dp_apply_dense (rows nobody looked up carry 0 and stay bit-identical).  Needs the
- * single-launch forward (cffm_dp_runs_ok(s, B)). */
+ * single-launch forward (cffm_dp_runs_ok(s, B)).
+ * CONTRACT of the image: all zeros on entry of cffm_dp_local_dense (which only writes the rows this rank looked up), all
+ * zeros again on return of cffm_dp_apply_dense (it clears every element it reads).  The caller zeroes the buffer ONCE,
+ * when it allocates it, and after any step it abandoned between the two calls. */
 int64_t cffm_dp_dense_floats(const cffm_shape_t *s);
 int cffm_dp_local_dense(const cffm_shape_t *s, const cffm_tables_t *tab, const float *theta, const int32_t *ids,
                         const float *y, int32_t B, int64_t B_global, void *ws, float *flat, void *stream);
 int cffm_dp_apply_dense(const cffm_shape_t *s, const cffm_tables_t *tab, const cffm_tables_t *acc, float *theta,
-                        float *theta_acc, const float *flat_sum, int64_t B_global, float *loss_out, void *stream);
+                        float *theta_acc, float *flat_sum, int64_t B_global, float *loss_out, void *stream);
 /* Data-parallel halves (cffm_amd/dist.py).  cffm_backward_unscaled = cffm_backward with dL/dout = (out - y) / B_global,
  * i.e. without the 1/L of the RMSE-style loss (CFFM.py:493), which needs the loss-term sum over the GLOBAL batch:
  * grad must hold theta.n + 4 floats, grad[theta.n] receives this rank's loss-term sum so that one all-reduce carries
