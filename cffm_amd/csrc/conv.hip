@@ -23,6 +23,8 @@
 #include <cstring>
 
 #include "internal.hpp"
+
+#include <stdlib.h>
 #include "inner_body.hpp"
 #include "head_body.hpp"
 #include "sort_body.hpp"
@@ -2726,9 +2728,195 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_wgrad_kernel(Wgrad
     }
 }
 
+// Round 3: the same contraction with ALL (dh,i) groups of a (q tile, slab) in ONE workgroup of 16 wavefronts (group = wave >> 2,
+// four wavefronts and four units each).  The version above gives every group a workgroup of its own, and each of them stages the
+// SAME dC tile: rocprofv3 counted 51.6 GB of FETCH_SIZE per launch (103 GB with the gfx950 correction) against a 16.6 GB dC_0 -
+// the four workgroups of a tile sit on one XCD but drift apart, so the L2 does not catch the re-reads, and at 3.7 TB/s the kernel was
+// bound by that traffic.  Here the tile is staged once per (example, column tile) and feeds the four groups out of LDS (dCt 32 KB
+// shared + one dT block of 16 KB per group + the embedding tile = 105 KB: one workgroup of 16 wavefronts per CU, the same number of
+// wavefronts per CU as two 8-wavefront workgroups).
+// The dC tile of the NEXT (example, column tile) and the embedding rows of the next example go HBM/L2 -> LDS directly
+// (global_load_lds: 16-byte pieces land at 16 x their index, which IS the dCt layout; one 4-byte piece per lane = one embedding
+// row per wave instruction at the padded pitch) into the other half of a double buffer while the current tile is computed: two
+// barriers per tile instead of three and no load latency in front of phase C.
+// GPW groups per workgroup (4: the tile is read once, 4 units per wavefront and 64 accumulation registers; 2: read twice, 2 units per
+// wavefront, 32 accumulation registers and nothing spilled under the 128-register budget of a 1024-thread workgroup)
+template <int SMAX, int GPW>
+__global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradArgs a, int nslab) {
+    constexpr int NTH = 1024, WPG = 16 / GPW, UPW = 16 / WPG;   // wavefronts per group; units (and phase-C columns) per wavefront
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, PpT = a.Pp, P = a.P, G = (2 * F + 15) / 16;
+    const int EsN = (F * Dp + 3) / 4 * 4;
+    float* Es0 = reinterpret_cast<float*>(smem);               // [2][F][Dp]
+    float* dCt0 = Es0 + 2 * EsN;                                // [2][S][16 x][16 q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int slab = bid % nslab; bid /= nslab;
+    const int gp = bid % (4 / GPW), qt = bid / (4 / GPW), q0 = qt * 16;          // gp: which GPW of the four groups this workgroup carries
+    const int gl = __builtin_amdgcn_readfirstlane(wave / WPG), g = gp * GPW + gl;   // group (scalar)
+    const int wl = wave % WPG, gtid = tid % (64 * WPG);                             // wave / thread inside the group
+    float* dTg = dCt0 + 2 * SMAX * 256 + gl * 4096;             // [16 m][16 x][16 q] of this group
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride;
+    float* sb = a.slabB + (int64_t)slab * a.slabB_stride;
+    const bool g_on = g < G;                                    // F < 32: the last groups only keep the barriers
+    const int mC = g * 16 + r;                                  // phase C row of this lane
+    const bool mC_ok = g_on && mC < 2 * F;
+    const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+    f32x4 accD[UPW][4];
+#pragma unroll
+    for (int u4 = 0; u4 < UPW; ++u4)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) accD[u4][t4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                          // bias partial of channel q0 + (gtid & 15), rows gtid >> 4 (group 0 only)
+    // fetch of tile (b, xt) into buffer `buf`: dC pieces e4 = tid, tid + 1024 (S * 64 of them), embedding rows f = wave, wave + 16
+    auto fetch_tile = [&](int b, int xt, int buf) {
+        const int x0 = xt * 16;
+        for (int e0 = wave * 64; e0 < S * 64; e0 += NTH) {
+            const int e4 = e0 + lane, q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
+            __builtin_amdgcn_global_load_lds(
+                (const void __attribute__((address_space(1)))*)(a.dC + (((int64_t)b * S + y) * S + x0 + x) * PpT + q0 + 4 * q4),
+                (void __attribute__((address_space(3)))*)(dCt0 + buf * SMAX * 256 + e0 * 4), 16, 0, 0);
+        }
+    };
+    auto fetch_rows = [&](int b, int buf) {
+        for (int f = wave; f < F; f += 16) {
+            const float* row = row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D);
+            if (lane < D)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + lane),
+                                                 (void __attribute__((address_space(3)))*)(Es0 + buf * EsN + f * Dp), 4, 0, 0);
+        }
+    };
+    int it = 0;                                                // tiles done: tile `it` lives in buffer it & 1, its rows in (it / RT) & 1
+    if (slab < a.B) { fetch_rows(slab, 0); fetch_tile(slab, 0, 0); }
+    for (int b = slab; b < a.B; b += nslab) {
+        const float* Es = Es0 + ((it / RT) & 1) * EsN;
+        for (int xt = 0; xt < RT; ++xt, ++it) {
+            const int x0 = xt * 16;
+            const float* dCt = dCt0 + (it & 1) * SMAX * 256;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` (and of its rows) have landed
+            __syncthreads();                                   // ... and everybody's; phase D of the previous tile is over
+            {   // the next tile, and with the last column tile of an example the rows of the next example
+                const bool last_x = xt + 1 == RT;
+                const int nb = last_x ? b + nslab : b, nxt = last_x ? 0 : xt + 1;
+                if (nb < a.B) {
+                    if (last_x) fetch_rows(nb, ((it + 1) / RT) & 1);
+                    fetch_tile(nb, nxt, (it + 1) & 1);
+                }
+            }
+            if (g == 0) {                                      // db[q] += sum_{y,x} dC: thread (q = gtid & 15, part = gtid >> 4)
+                const int q = gtid & 15, part = gtid >> 4;
+                for (int e = part; e < S * 16; e += 4 * WPG) bsum += dCt[e * 16 + q];
+            }
+            // ---- phase C: dT rows mC (this group), wave's x columns 4*wl .. 4*wl+3 -----------------------------------
+            if (g_on) {
+                f32x4 acc[UPW];
+#pragma unroll
+                for (int xl = 0; xl < UPW; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int s4 = 0; s4 < S / 4; ++s4) {
+                    const int y = 4 * s4 + kk;
+                    const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
+#pragma unroll
+                    for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[(y * 16 + UPW * wl + xl) * 16 + r], acc[xl]);
+                }
+#pragma unroll
+                for (int xl = 0; xl < UPW; ++xl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wl + xl) * 16 + r] = acc[xl][j];
+            }
+            __syncthreads();
+            // ---- phase D: the wave's four units -----------------------------------------------------------------------
+            if (g_on) {
+                // The per-(unit, tile) row offsets below are loop invariants; hoisted out of the tile loop they do not fit the
+                // 128-register budget next to the 64 accumulation registers and come back as scratch reloads (two L2 round
+                // trips in front of every block of 16 MFMAs: 28.2 ms).  An opaque zero keeps their six VALU instructions here.
+                int opq;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+#pragma unroll
+                for (int u4 = 0; u4 < UPW; ++u4) {
+                    const int ml = wl * UPW + u4, m = g * 16 + ml;
+                    if (m >= 2 * F) continue;
+                    const int dh = m >= F ? 1 : 0, i = m - dh * F;
+                    (void)dh;
+                    const int nj = F - 1 - i, K2 = 2 * nj;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        if (t4 * 16 >= K2) continue;
+                        const int m2 = t4 * 16 + r + opq;
+                        const bool ok = m2 < K2;
+                        const int dw = (ok && m2 >= nj) ? 1 : 0, jj = ok ? m2 - dw * nj : 0;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int x = 4 * s4 + kk;
+                            const float av = ok ? Es[(i + 1 + jj) * Dp + 2 * (x0 + x) + dw] : 0.f;
+                            accD[u4][t4] = mfma16(av, dTg[(ml * 16 + x) * 16 + r], accD[u4][t4]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's part of the slab ------------------------------------------------------------------
+    if (g_on) {
+#pragma unroll
+        for (int u4 = 0; u4 < UPW; ++u4) {
+            const int m = g * 16 + wl * UPW + u4;
+            if (m >= 2 * F) continue;
+            const int dh = m >= F ? 1 : 0, i = m - dh * F;
+            const int nj = F - 1 - i, K2 = 2 * nj, base = i * (2 * F - i - 1) / 2;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                if (t4 * 16 >= K2) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m2 = t4 * 16 + kk * 4 + j;
+                    if (m2 < K2) {
+                        const int dw = m2 >= nj ? 1 : 0, jj = m2 - dw * nj;
+                        sw[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] = accD[u4][t4][j];
+                    }
+                }
+            }
+        }
+    }
+    // rows of padded pairs (p >= P) are never produced: they must read as zeros in the reduction
+    for (int e = tid; e < 4 * (PpT - P) * 16 && gp == 0; e += NTH) {
+        const int q = e & 15, rest = e >> 4, p = P + rest % (PpT - P), tap = rest / (PpT - P);
+        sw[((int64_t)tap * PpT + p) * PpT + q0 + q] = 0.f;
+    }
+    __syncthreads();                                           // every group is done with the tiles
+    float* red = dCt0;                                         // [4 * WPG parts][16 q]
+    if (g == 0) red[(gtid >> 4) * 16 + (gtid & 15)] = bsum;
+    __syncthreads();
+    if (gp == 0 && tid < 16) {
+        float v = 0.f;
+#pragma unroll
+        for (int part = 0; part < 4 * WPG; ++part) v += red[part * 16 + tid];
+        sb[q0 + tid] = v;
+    }
+}
+
 static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream_t st) {
     const int S = a.D / 2, G = (2 * a.F + 15) / 16;
     if (S > 32) return CFFM_ERR_UNSUPPORTED;
+    const char* ver = getenv("CFFM_TILE_WGRAD");                // debug: 1 = round-2 kernel, 4 = four groups per workgroup
+    if (G <= 4 && !(ver && ver[0] == '1')) {
+        if (ver && ver[0] == '4') {
+            const size_t lds = (size_t)(2 * ((a.F * (a.D + 1) + 3) / 4 * 4) + 2 * 32 * 256 + 4 * 16 * 256) * 4 + 16;
+            int rc = set_lds(conv0_fact_tile_wgrad_all_kernel<32, 4>, lds);
+            if (rc) return rc;
+            const int64_t grid = (int64_t)(a.Pp / 16) * nslab;
+            hipLaunchKernelGGL((conv0_fact_tile_wgrad_all_kernel<32, 4>), dim3((unsigned)grid), dim3(1024), lds, st, a, nslab);
+            CFFM_CHECK_LAUNCH();
+            return 0;
+        }
+        // two groups per workgroup of 16 wavefronts: the tile is staged twice instead of four times, nothing spills
+        const size_t lds = (size_t)(2 * ((a.F * (a.D + 1) + 3) / 4 * 4) + 2 * 32 * 256 + 2 * 16 * 256) * 4 + 16;
+        int rc = set_lds(conv0_fact_tile_wgrad_all_kernel<32, 2>, lds);
+        if (rc) return rc;
+        const int64_t grid = (int64_t)(a.Pp / 16) * 2 * nslab;
+        hipLaunchKernelGGL((conv0_fact_tile_wgrad_all_kernel<32, 2>), dim3((unsigned)grid), dim3(1024), lds, st, a, nslab);
+        CFFM_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = (size_t)((a.F * (a.D + 1) + 3) / 4 * 4 + 32 * 256 + 16 * 256) * 4 + 16;
     constexpr int NW = 8;
     int rc = set_lds(conv0_fact_tile_wgrad_kernel<32, NW>, lds);
@@ -2781,6 +2969,29 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt) accB[g][yt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* dCb = a.dC + (int64_t)b * S * S * PpT;
+    // The dC tile of the NEXT (column tile, channel tile) is fetched into registers while the current one is worked on (two
+    // wavefronts per SIMD do not hide a global load that is issued and consumed in the same step: 4 of the 64 ms).  Measured and
+    // not kept: the filter slices of phase E requested two phases ahead as well (64 more registers: 256 with spills and
+    // scratch-resident operand arrays, 64 -> 104 ms).
+    constexpr int NX = SMAX * 64 / NTH;                        // 16-byte pieces of a tile per thread
+    static_assert(NX == 8, "the prefetch registers are eight named float4s (an array ends up in scratch memory here)");
+    float4 nx0, nx1, nx2, nx3, nx4, nx5, nx6, nx7;
+#define CFFM_TILE_FETCH(X0N, Q0N)                                                                                              \
+    do {                                                                                                                      \
+        const float* tb_ = dCb + (int64_t)(X0N) * PpT + (Q0N) + 4 * (tid & 3) + (int64_t)((tid >> 2) & 15) * PpT;              \
+        const int64_t ys_ = (int64_t)S * PpT;                  /* e4 = tid + u * 256: y = (tid >> 6) + 4u */                   \
+        const int y_ = tid >> 6;                                                                                              \
+        nx0 = *reinterpret_cast<const float4*>(tb_ + min(y_, S - 1) * ys_);                                                   \
+        nx1 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 4, S - 1) * ys_);                                               \
+        nx2 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 8, S - 1) * ys_);                                               \
+        nx3 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 12, S - 1) * ys_);                                              \
+        nx4 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 16, S - 1) * ys_);                                              \
+        nx5 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 20, S - 1) * ys_);                                              \
+        nx6 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 24, S - 1) * ys_);                                              \
+        nx7 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 28, S - 1) * ys_);                                              \
+    } while (0)
+    static_assert(NTH == 256, "y = (tid >> 6) + 4u above");
+    CFFM_TILE_FETCH(0, 0);
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt) {
         if (xt >= RT) continue;
@@ -2788,10 +2999,21 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
         for (int qt = 0; qt < QT; ++qt) {
             const int q0 = qt * 16;
             __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
-            for (int e4 = tid; e4 < S * 16 * 4; e4 += NTH) {   // the dC tile is staged ONCE for the four row groups
-                const int q4 = e4 & 3, x = (e4 >> 2) & 15, y = e4 >> 6;
-                *reinterpret_cast<float4*>(dCt + y * DCP + x * 16 + 4 * q4) =
-                    *reinterpret_cast<const float4*>(dCb + ((int64_t)y * S + x0 + x) * PpT + q0 + 4 * q4);
+            {                                                  // the dC tile is staged ONCE for the four row groups
+                float* tl_ = dCt + ((tid >> 2) & 15) * 16 + 4 * (tid & 3);
+                const int y_ = tid >> 6;
+                if (y_ < S) *reinterpret_cast<float4*>(tl_ + y_ * DCP) = nx0;
+                if (y_ + 4 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 4) * DCP) = nx1;
+                if (y_ + 8 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 8) * DCP) = nx2;
+                if (y_ + 12 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 12) * DCP) = nx3;
+                if (y_ + 16 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 16) * DCP) = nx4;
+                if (y_ + 20 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 20) * DCP) = nx5;
+                if (y_ + 24 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 24) * DCP) = nx6;
+                if (y_ + 28 < S) *reinterpret_cast<float4*>(tl_ + (y_ + 28) * DCP) = nx7;
+            }
+            {   // the next tile (clamped to the last one: a harmless re-read at the very end)
+                const bool nq = qt + 1 < QT, nxt = xt + 1 < RT;
+                CFFM_TILE_FETCH(nq ? x0 : (nxt ? x0 + 16 : x0), nq ? q0 + 16 : (nxt ? 0 : q0));
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -2939,6 +3161,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
     }
 }
 
+#undef CFFM_TILE_FETCH
 static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
     const int S = a.D / 2;
     if (S > 32 || 2 * a.F > 64) return CFFM_ERR_UNSUPPORTED;
