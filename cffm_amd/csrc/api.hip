@@ -92,6 +92,13 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
         out->Go = take((int64_t)s->M * s->D * 4);
         out->Gfb = take((int64_t)s->M * 4);
     }
+    if (s->outer_conv) {
+        for (int l = 0; l < g.live; ++l) {
+            const int np = pool_partials(g, l);
+            out->pool_np[l] = np;
+            if (np > 0) out->pool[l] = take(b * (g.D >> (l + 1)) * np * 4);
+        }
+    }
     out->bytes = o;
     return 0;
 }

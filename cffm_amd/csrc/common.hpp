@@ -77,6 +77,40 @@ static inline int check_shape(const cffm_shape_t* s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide filters (Pp > 64): which kernel runs layer 0, how the conv GEMMs cut their columns, and the partial sum pools the conv
+// epilogues leave for the head (shared by the workspace layout in api.hip and the kernels in conv.hip / head.hip).
+// ---------------------------------------------------------------------------------------------
+#define C0T_MAXKS 16      // k-steps of one step-1 unit of the tiled layer 0: 2(F-1)/4 <= 16 for F <= 32
+static inline bool conv0_fact_tile_ok(const Geo& g) {
+    const int S = g.D / 2;
+    return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
+}
+static inline bool conv0_tile_fwd_ok(const Geo& g) { return conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS; }
+// column tiles of 16 -> column blocks of NT tiles (NT in {1,2,3,4,6,8}) of the implicit-GEMM kernels
+static inline void pick_nt(int tiles, int* nblk, int* NT) {
+    int nb = (tiles + 7) / 8;
+    int need = (tiles + nb - 1) / nb;
+    static const int allowed[6] = {1, 2, 3, 4, 6, 8};
+    int nt = 8;
+    for (int i = 0; i < 6; ++i)
+        if (allowed[i] >= need) { nt = allowed[i]; break; }
+    *NT = nt;
+    *nblk = (tiles + nt - 1) / nt;
+}
+// Sum pools of the wide shapes (CFFM.py:390-391): s_{l+1}[b][y] = sum_{x,q} act(C_l[b][y][x][q]).  Round 2's head swept the conv
+// outputs again for them (21.7 GB at the stress shape: 3.7 ms, HBM-bound on values the conv epilogues just had in registers).
+// Now every epilogue leaves, per (example, row y), ONE partial per column block (layers >= 1) or per (column tile, channel tile)
+// (tiled layer 0), in a fixed place; the head adds the pool_partials(g, l) partials of a row in index order (bitwise reproducible).
+// 0: this shape keeps the sweep.
+static inline int pool_partials(const Geo& g, int l) {
+    if (g.Pp <= 64 || g.D / 2 > 64) return 0;              // rows of one y must fit the smallest row tile (64 rows)
+    if (l == 0 && conv0_tile_fwd_ok(g)) return (g.D / 2 / 16) * (g.Pp / 16);
+    int nblk, NT;
+    pick_nt(g.Pp / 16, &nblk, &NT);
+    return nblk;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Where the looked-up rows of a [B,F] id batch are read from (tf.nn.embedding_lookup, CFFM.py:303, :354, :422).
 //   idx == nullptr  the copy a gather left in the workspace: row `slot` (= b*F + f) of base [B*F][dim]
 //   idx != nullptr  straight from the table: row clamp(idx[slot]) of base [M][dim].  The wide shapes (Pp > 64) run this
@@ -304,6 +338,16 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0x142, 0xa>(v, ninf));
     v = fmaxf(v, dpp_mov<0x143, 0xc>(v, ninf));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over the 8 (SIXTEEN = false) or 16 consecutive lanes of a DPP row; every lane of the group ends with it
+template <bool SIXTEEN>
+__device__ __forceinline__ float row_group_sum(float v) {
+    v += dpp_mov<0xB1, 0xf>(v, 0.f);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v, 0.f);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v, 0.f);    // row_half_mirror: 8 lanes
+    if (SIXTEEN) v += dpp_mov<0x140, 0xf>(v, 0.f);   // row_mirror: 16 lanes
+    return v;
 }
 
 // Block-wide sum in a fixed order (bitwise reproducible); red must hold >= blockDim/64 floats.

@@ -189,6 +189,8 @@ struct ConvArgs {
     int dbg;             // debug build only (make TILE_DBG=1): phase-skipping bits for tools/dbg_tile.py, 0 otherwise
     const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = `in` is the outer TABLE [M][D] and row (b, f) is idx[b*F+f] (RowSrc)
     int idxM = 0;
+    float* pool = nullptr;          // wide shapes: partial sum pools of act(out), [B][So][pool_np] (pool_partials(), common.hpp)
+    int pool_np = 0;
 };
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
@@ -270,6 +272,12 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, GEN ? CFFM_ACT_RELU : a.act);   // act(C_{l-1}) on the A operand
 
+    float psum[RM][4];                                         // pool partials: this lane's column of every row it holds
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) psum[rm][j] = 0.f;
+    const int pact = GEN ? CFFM_ACT_RELU : a.act;              // (the pools apply self.activation to the stored relu output, :387)
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
 #pragma unroll
@@ -280,7 +288,33 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
-                if (m < a.Mtot) a.out[m * Pp + n] = fmaxf(acc[rm][nt][j] + bv, 0.f);   // CFFM.py:478
+                const float c = fmaxf(acc[rm][nt][j] + bv, 0.f);                       // CFFM.py:478
+                if (m < a.Mtot) a.out[m * Pp + n] = c;
+                psum[rm][j] += act_pos(c, a.act);              // padded channels: zero filter and bias -> act(0) = 0
+            }
+        }
+    }
+    (void)pact;
+    if (a.pool != nullptr) {
+        // s_{l+1}[b][y] partial of this column block: columns over the 16 lanes of a DPP row, then the So rows (x) of one y in
+        // row order out of LDS (the filter tiles are dead; So <= 64 <= BM and both are powers of two: a y never straddles tiles)
+        float* rowsum = Ws;                                    // [BM]
+        __syncthreads();                                       // every wave is done with the filter tiles
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = row_group_sum<true>(psum[rm][j]);
+                if (r == 0) rowsum[wave * (16 * RM) + rm * 16 + kk * 4 + j] = v;
+            }
+        __syncthreads();
+        const int ny = BM >> a.lgSo;                           // (b, y) groups of this row tile
+        if (tid < ny) {
+            const int64_t m = m0 + ((int64_t)tid << a.lgSo);
+            if (m < a.Mtot) {
+                float v = 0.f;
+                for (int x = 0; x < So; ++x) v += rowsum[(tid << a.lgSo) + x];
+                a.pool[(m >> a.lgSo) * a.pool_np + (n0 / BN)] = v;          // m >> lgSo = b * So + y
             }
         }
     }
@@ -2360,17 +2394,6 @@ __global__ __launch_bounds__(256) void bwd_top_kernel(BwdTopArgs a) {
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-static inline void pick_nt(int tiles, int* nblk, int* NT) {
-    int nb = (tiles + 7) / 8;
-    int need = (tiles + nb - 1) / nb;
-    static const int allowed[6] = {1, 2, 3, 4, 6, 8};
-    int nt = 8;
-    for (int i = 0; i < 6; ++i)
-        if (allowed[i] >= need) { nt = allowed[i]; break; }
-    *NT = nt;
-    *nblk = (tiles + nt - 1) / nt;
-}
-
 #define DISPATCH_NT(NTV, CALL)                     \
     switch (NTV) {                                 \
         case 1: { constexpr int NT_ = 1; CALL; } break; \
@@ -2493,7 +2516,6 @@ static int launch_conv_fwd_rows(const ConvArgs& a, hipStream_t st) {
 // 15.7x fewer MFMAs than the direct contraction at F = 32, D = 64 (128 MFLOP against 2,015 per example).  W fragments come
 // straight from L2 (a 16-channel column slice of the filter, 127 KB, shared by every example of the tile: the grid is
 // tile-major); T (2F planes of 16 x 16, 70 KB: two workgroups per CU) and the embedding tile live in LDS.
-#define C0T_MAXKS 16      // k-steps of one step-1 unit: 2(F-1)/4 <= 16 for F <= 32
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArgs a) {
     constexpr int NTH = 64 * NW, XQ = 16 / NW;
@@ -2502,6 +2524,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
     constexpr int TP = 16 * 16 + 16;
     float* T = reinterpret_cast<float*>(smem);                 // [2F][TP]
     float* Es = T + 2 * F * TP;                                 // [F][Dp]
+    float* PS = Es + F * Dp;                                    // [NW][S] pool partials of the wavefronts
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     int bid = blockIdx.x;
     const int b = bid % a.B; bid /= a.B;
@@ -2588,6 +2611,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
 #pragma unroll
             for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = mfma16(av, ok ? tb[q4 * 16] : 0.f, acc[q4]);
         }
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
@@ -2596,7 +2620,24 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
                 const float c = fmaxf(acc[q4][j] + bias, 0.f);
                 if (!(dbg & 1) || c == 12345.678f)
                     a.out[(((int64_t)b * S + yy) * S + x0 + xg + q4) * PpT + q0 + r] = c;
+                ps[j] += act_pos(c, a.act);
             }
+        if (a.pool != nullptr) {                                // pool partial of this (column tile, channel tile): over q in the DPP row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = row_group_sum<true>(ps[j]);
+                if (r == 0) PS[(wave * RT + rt) * 16 + kk * 4 + j] = v;          // [NW][S], behind the embedding tile
+            }
+        }
+    }
+    if (a.pool != nullptr) {
+        lds_barrier();
+        if (tid < S) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += PS[w * S + tid];                      // wave order: x0 + w * XQ ascending
+            a.pool[((int64_t)b * S + tid) * a.pool_np + xt * (PpT / 16) + qt] = v;
+        }
     }
 }
 
@@ -3175,15 +3216,10 @@ static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
     return 0;
 }
 
-static inline bool conv0_fact_tile_ok(const Geo& g) {
-    const int S = g.D / 2;
-    return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
-}
-
 static int launch_conv0_fact_tile_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int NW = 8;                // measured at F32 D64 B8192: 38.6 ms with 4 wavefronts, 29.2 with 8, 36.6 with 16 (one workgroup per CU)
     const int S = a.D / 2;
-    const size_t lds = (size_t)(2 * a.F * (16 * 16 + 16) + a.F * (a.D + 1)) * 4 + 16;
+    const size_t lds = (size_t)(2 * a.F * (16 * 16 + 16) + a.F * (a.D + 1) + NW * S) * 4 + 16;
     int rc = set_lds(conv0_fact_tile_fwd_kernel<NW>, lds);
     if (rc) return rc;
     const int64_t grid = (int64_t)a.B * (a.Pp / 16) * (S / 16);
@@ -3357,6 +3393,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     a.out = (float*)(w + wl.C[l]);
     a.Mtot = layer_rows(g, B, l, &a.lgSo);
     a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
+    if (wl.pool_np[l] > 0) { a.pool = (float*)(w + wl.pool[l]); a.pool_np = wl.pool_np[l]; }   // wide shapes: the epilogue leaves the pool partials
     int nblk, NT;
     int rc = 0;
     if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop

@@ -69,6 +69,10 @@ int cffm_head_fwd_impl2(const cffm_shape_t* s, const float* theta, void* ws, con
     a.out = (float*)(w + wl.out); a.sqerr = (float*)(w + wl.sqerr);
     a.loss = s->loss; a.inner_conv = s->inner_conv; a.outer_conv = s->outer_conv;
     a.s0_ready = (s0_ready && s->outer_conv && s->D <= 256) ? 1 : 0;
+    for (int l = 0; l < CFFM_MAX_LAYERS; ++l) {
+        a.pool_np[l] = wl.pool_np[l];
+        a.pool[l] = wl.pool_np[l] > 0 ? (const float*)(w + wl.pool[l]) : nullptr;
+    }
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), head_fwd_lds(a.g), (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     if (y && do_sum) {

@@ -14,6 +14,8 @@ struct HeadArgs {
     float *t1, *h1, *att, *out, *sqerr;
     int loss, inner_conv, outer_conv;
     int s0_ready = 0;         // 1: t1[b][0:D] already holds the s0 pool (cffm_gather_inner_fwd_wide wrote it) and Eo is not read
+    const float* pool[CFFM_MAX_LAYERS] = {};   // wide shapes: partial sum pools left by the conv epilogues, [B][S_l][pool_np[l]]
+    int pool_np[CFFM_MAX_LAYERS] = {};         // 0: sweep C_l here
 };
 
 __device__ __forceinline__ float loss_term(float out_raw, float y, int loss, float* out_eval) {
@@ -122,6 +124,17 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         int off = g.D;
         for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
             const int S = g.D >> (l + 1);
+            if (!CL && a.pool_np[l] > 0) {                          // the conv epilogue left the partials: add them up in index order
+                const int np = a.pool_np[l];
+                for (int y = tid; y < S; y += NTH) {
+                    const float* pp = a.pool[l] + ((int64_t)b * S + y) * np;
+                    float v = 0.f;
+                    for (int k = 0; k < np; ++k) v += pp[k];
+                    t1s[off + y] = v;
+                }
+                off += S;
+                continue;
+            }
             const int n4 = S * g.Pp / 4;
             const float4* base = CL ? reinterpret_cast<const float4*>(smem + fused_c_off(l, c0_off, c1_off, g.D, g.Pp))
                                     : reinterpret_cast<const float4*>(a.C[l] + (int64_t)b * S * S * g.Pp);

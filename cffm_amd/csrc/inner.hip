@@ -111,16 +111,6 @@ struct GatherInnerWideArgs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// sum over the D4 (8 or 16) consecutive lanes that hold one row, on the DPP path; every lane of the group ends with it
-template <bool SIXTEEN>
-__device__ __forceinline__ float row_group_sum(float v) {
-    v += dpp_mov<0xB1, 0xf>(v, 0.f);     // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E, 0xf>(v, 0.f);     // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141, 0xf>(v, 0.f);    // row_half_mirror: 8 lanes
-    if (SIXTEEN) v += dpp_mov<0x140, 0xf>(v, 0.f);   // row_mirror: 16 lanes
-    return v;
-}
-
 // FS > 0: the field count as a compile-time constant (with K == D == 2*K2 this fixes the LDS image: every per-example offset of
 // the unit loop becomes an immediate of its ds_read_b64 instead of a v_add per read)
 template <int K2, int UPT, int ACTC, int FS>

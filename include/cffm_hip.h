@@ -101,6 +101,9 @@ typedef struct cffm_ws_layout {
     int64_t sort_tmp;                       /* radix sort scratch                                  */
     int64_t sort_tmp_bytes;
     int64_t Gi, Go, Gfb;                    /* dense table gradients [M,K], [M,D], [M] (CFFM_LOSS_SQUARE_L2, CFFM_OPT_ADAM) */
+    int64_t pool[CFFM_MAX_LAYERS];          /* wide shapes (Pp > 64): partial sum pools of act(C_l) left by the conv epilogues,
+                                               [B][S_l][pool_np[l]] floats (0 = not used); the head adds the partials up       */
+    int32_t pool_np[CFFM_MAX_LAYERS];       /* partials per (example, row y) of layer l                                          */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
