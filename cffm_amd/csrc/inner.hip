@@ -55,10 +55,13 @@ extern "C" int cffm_inner_bwd(const cffm_shape_t* s, const float* theta, void* w
     return cffm_inner_bwd_rows(s, theta, ws, B, nullptr, (hipStream_t)stream);
 }
 
+int cffm_inner_bwd_wide(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t stream);
+
 int cffm_inner_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t stream) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0 || !s->inner_conv) return 0;
+    if (cffm_wide_regather_ok(s) && !getenv("CFFM_INNER_BWD_V1")) return cffm_inner_bwd_wide(s, theta, ws, B, rs, stream);
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
     cffm_theta_layout(s, &tl); cffm_ws_layout(s, B, &wl);
     const Geo g = make_geo(s);
@@ -394,4 +397,186 @@ extern "C" int cffm_gather_inner_fwd(const cffm_shape_t* s, const cffm_tables_t*
     if (rc) return rc;
     if (!t || !theta || !ids || !ws) return CFFM_ERR_BAD_SHAPE;
     return cffm_gather_inner_fwd_wide(s, t, theta, ids, B, ws, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the inner branch for the wide shapes (same applicability as cffm_gather_inner_fwd_wide).  inner_bwd_body was
+// written for the README shapes: one 256-thread workgroup per example, the dense(1) kernel gradient read-modify-written in the
+// global slab once per unit and example (2 GB of L2 traffic at the stress shape), dE in four LDS planes fed by ds_add_f32:
+// 2.96 ms at F32 K64 B8192.  Here thread (f, t) owns the two floats dEi[f][2t], dEi[f][2t+1] of every example of its slab and
+// walks the F-1 partners j of row f: the unit (pair {f, j}, t) is evaluated from BOTH of its rows (twice the arithmetic, no atomics,
+// no cross-thread sums: dEi accumulates in two registers in a fixed partner order), the side with f < j also owns the unit's
+// dense-kernel gradient - 2 x (F-1-f) register accumulators that are written to the slab ONCE - and the conv-filter / bias
+// gradients.  Rows come HBM/L2 -> LDS by global_load_lds (next example in flight behind the current one).
+// ---------------------------------------------------------------------------------------------------------------------
+struct InnerBwdWideArgs {
+    RowSrc rows;                            // inner rows: ws.Ei (idx == NULL) or the inner table + the batch's ids
+    const float *dout, *out, *y;            // dout == NULL: dL/dout = head_dout(loss, out[b], y[b], invB, L) on the fly (as inner_bwd_body)
+    const float *cw, *cb, *wd;
+    float* dEi;                             // [B][F][K]
+    float *slab_cw, *slab_cb, *slab_dw, *slab_db;     // slab 0
+    int64_t slab_stride;
+    int B, F, K, P, act, loss;
+    float invB, L;
+};
+
+template <int K2, int ACTC>
+__global__ __launch_bounds__(1024) void inner_bwd_wide_kernel(InnerBwdWideArgs a) {
+    constexpr int T = 1024, K = 2 * K2, K4 = K / 4, NJ = 31;   // NJ: partners of a row at F = 32
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* E0 = reinterpret_cast<float*>(smem);                // [2][F][K] rows of the current / next example
+    float* red = E0 + 2 * 32 * K;                               // [16 waves][8]
+    float* dWl = red + 16 * 8;                                  // [P][K] dense(1) kernel gradient of this slab: every (pair, t) element
+                                                                // belongs to ONE thread, which adds to it once per example (64 registers
+                                                                // per lane if kept there: 245 spilled under the 128-register budget)
+    const int F = a.F, act = ACTC >= 0 ? ACTC : a.act;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = tid / K2, t = tid - f * K2;
+    const bool on = f < F;
+    const int slab = blockIdx.x, nslab = gridDim.x;
+    float* slab_cw = a.slab_cw + slab * a.slab_stride; float* slab_cb = a.slab_cb + slab * a.slab_stride;
+    float* slab_dw = a.slab_dw + slab * a.slab_stride; float* slab_db = a.slab_db + slab * a.slab_stride;
+    if (tid < 8) slab_cw[tid] = 0.f;                            // inner_cw (4) + inner_cb (2 + 2 pad): gaps read as zeros
+    if (tid < 4) slab_db[tid] = 0.f;
+    const float cw0 = a.cw[0], cw1 = a.cw[1], cw2 = a.cw[2], cw3 = a.cw[3], cb0 = a.cb[0], cb1 = a.cb[1];
+    const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
+    const int basef = on ? f * (2 * F - f - 1) / 2 : 0;        // first pair of row f on its i side
+    for (int e = tid; e < a.P * K2; e += T) reinterpret_cast<f32x2*>(dWl)[e] = (f32x2){0.f, 0.f};
+    float gcw[4] = {0.f, 0.f, 0.f, 0.f}, gcb[2] = {0.f, 0.f}, gdb = 0.f;
+    // fetch of the rows of example b into buffer buf: piece q = tid (16 bytes), 16 / 8 lanes per row
+    auto fetch = [&](int b, int buf) {
+        if (tid < F * K4) {
+            const int fr = tid / K4, c = tid - fr * K4;
+            const float* row = row_ptr(a.rows.base, a.rows.idx, a.rows.M, (int64_t)b * F + fr, K);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + 4 * c),
+                                             (void __attribute__((address_space(3)))*)(E0 + buf * 32 * K + wave * 256), 16, 0, 0);
+        }
+    };
+    int it = 0;
+    if (slab < a.B) fetch(slab, 0);
+    for (int b = slab; b < a.B; b += nslab, ++it) {
+        const float db = a.dout ? a.dout[b] : head_dout(a.loss, a.out[b], a.y[b], a.invB, a.L);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of example b have landed
+        __syncthreads();                                       // ... and everybody's; the other buffer is free again
+        if (b + nslab < a.B) fetch(b + nslab, (it + 1) & 1);
+        const float* E = E0 + (it & 1) * 32 * K;
+        if (on) {
+            const f32x2 ef = *reinterpret_cast<const f32x2*>(E + f * K + 2 * t);
+            f32x2 accF = (f32x2){0.f, 0.f};
+            // the pair index and row offset of every partner are invariants of the example loop; hoisted out of it they are ~100
+            // registers (374 spilled): an opaque zero keeps their handful of integer instructions inside the loop
+            int fo;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(fo) : "v"(f));
+            // partners in chunks of four: the four (row piece, weight pair) loads of a chunk are in flight together, and nothing
+            // moves across a chunk (left alone, hipcc hoists the 62 loads of ALL partners to the top: 114 spilled registers)
+#pragma clang loop unroll(full)
+            for (int c4 = 0; c4 < (NJ + 3) / 4; ++c4) {
+                f32x2 ejv[4], w2v[4];
+                int pv[4];
+#pragma clang loop unroll(full)
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = 4 * c4 + u;
+                    int j = fo + 1 + jj;
+                    const bool iside = j < F;                   // row f is the first row of the pair: this thread owns the unit's dense gradients
+                    j = iside ? j : j - F;
+                    const bool live = jj < F - 1;
+                    j = live ? j : 0;
+                    pv[u] = live ? (iside ? fo * (2 * F - fo - 1) / 2 + jj : j * (2 * F - j - 1) / 2 + (fo - j - 1)) : 0;
+                    ejv[u] = *reinterpret_cast<const f32x2*>(E + j * K + 2 * t);
+                    w2v[u] = wd2[(int64_t)pv[u] * K2 + t];      // 127 KB vector, L2-resident
+                }
+#pragma clang loop unroll(full)
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = 4 * c4 + u;
+                    if (jj >= NJ) continue;
+                    const bool iside = fo + 1 + jj < F, live = jj < F - 1;
+                    const f32x2 ej = ejv[u], w2 = w2v[u];
+                    // forward of the unit (CFFM.py:310-332), as inner_unit()
+                    const float I0 = ef.x * ej.x, I1 = ef.y * ej.y;
+                    const float x0 = act_f(I0, act), x1 = act_f(I1, act);
+                    const float z0 = x0 * cw0 + x1 * cw2 + cb0, z1 = x0 * cw1 + x1 * cw3 + cb1;
+                    const float r0 = fmaxf(z0, 0.f), r1 = fmaxf(z1, 0.f);
+                    // backward
+                    const float dbl = live ? db : 0.f;          // F < 32: the surplus partners contribute exact zeros
+                    const float ds0 = dbl * w2.x, ds1 = dbl * w2.y;
+                    const float dz0 = ds0 * act_relu_grad(r0, act), dz1 = ds1 * act_relu_grad(r1, act);
+                    const float dmp = ds0 + ds1;
+                    const bool firstmax = x0 >= x1;             // max-pool grad: first element on ties
+                    const float dx0 = dz0 * cw0 + dz1 * cw1 + (firstmax ? dmp : 0.f);
+                    const float dx1 = dz0 * cw2 + dz1 * cw3 + (firstmax ? 0.f : dmp);
+                    const float dI0 = dx0 * act_grad_f(I0, act), dI1 = dx1 * act_grad_f(I1, act);
+                    accF.x += dI0 * ej.x; accF.y += dI1 * ej.y; // dEi[f] += dI (.) e_j, partners in a fixed order
+                    const float di = iside ? dbl : 0.f;         // the i side owns the unit's parameter gradients
+                    const float mp = fmaxf(x0, x1);
+                    if (iside && live) {                        // dense(1) kernel gradient: flat * dout, into this thread's own LDS element
+                        f32x2* dwp = reinterpret_cast<f32x2*>(dWl) + pv[u] * K2 + t;
+                        f32x2 dv = *dwp;
+                        dv.x += (act_pos(r0, act) + mp) * di;
+                        dv.y += (act_pos(r1, act) + mp) * di;
+                        *dwp = dv;
+                    }
+                    const float e0 = iside ? dz0 : 0.f, e1 = iside ? dz1 : 0.f;
+                    gcw[0] += e0 * x0; gcw[1] += e1 * x0; gcw[2] += e0 * x1; gcw[3] += e1 * x1;
+                    gcb[0] += e0; gcb[1] += e1;
+                }
+                // (all seven accumulators are pinned: pinning accF alone made the compiler sink the 6 filter / bias gradient
+                // updates of every partner to the end of the example and keep their operands in scratch until then)
+                asm volatile("" : "+v"(accF), "+v"(gcw[0]), "+v"(gcw[1]), "+v"(gcw[2]), "+v"(gcw[3]), "+v"(gcb[0]), "+v"(gcb[1]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            *reinterpret_cast<f32x2*>(a.dEi + ((int64_t)b * F + f) * K + 2 * t) = accF;
+        }
+        if (tid == 0) gdb += db;
+    }
+    // the slab: this thread's units of the dense(1) kernel gradient (zeros when the slab saw no example)
+    __syncthreads();
+    for (int e = tid; e < a.P * K2; e += T) reinterpret_cast<f32x2*>(slab_dw)[e] = reinterpret_cast<const f32x2*>(dWl)[e];
+    float r[7] = {gcw[0], gcw[1], gcw[2], gcw[3], gcb[0], gcb[1], gdb};
+#pragma unroll
+    for (int q = 0; q < 7; ++q) r[q] = wave_sum(r[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[wave * 8 + q] = r[q];
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            float v = 0.f;
+            for (int w = 0; w < 16; ++w) v += red[w * 8 + q];
+            r[q] = v;
+        }
+        for (int q = 0; q < 4; ++q) slab_cw[q] = r[q];
+        slab_cb[0] = r[4]; slab_cb[1] = r[5];
+        slab_db[0] = r[6];
+    }
+}
+
+template <int K2>
+static int launch_ibw(const InnerBwdWideArgs& a, int nslab, hipStream_t st) {
+    const size_t lds = (size_t)(2 * 32 * 2 * K2 + 16 * 8 + a.P * 2 * K2) * 4;
+    hipError_t e1 = hipFuncSetAttribute((const void*)inner_bwd_wide_kernel<K2, CFFM_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)inner_bwd_wide_kernel<K2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    if (a.act == CFFM_ACT_RELU) hipLaunchKernelGGL((inner_bwd_wide_kernel<K2, CFFM_ACT_RELU>), dim3(nslab), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((inner_bwd_wide_kernel<K2, -1>), dim3(nslab), dim3(1024), lds, st, a);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// rs == NULL: rows from ws.Ei.  Returns CFFM_ERR_UNSUPPORTED for shapes outside cffm_wide_regather_ok().
+int cffm_inner_bwd_wide(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t stream) {
+    if (!cffm_wide_regather_ok(s) || s->F > 32) return CFFM_ERR_UNSUPPORTED;
+    if (B <= 0) return 0;
+    InnerBwdArgs o;
+    const int nslab = fill_inner_bwd_args(s, theta, ws, B, &o);
+    InnerBwdWideArgs a;
+    a.rows.base = rs ? rs->base : o.Ei; a.rows.idx = rs ? rs->idx : nullptr; a.rows.M = rs ? rs->M : 0;
+    a.dout = o.dout; a.out = o.out; a.y = o.y; a.cw = o.cw; a.cb = o.cb; a.wd = o.wd; a.dEi = o.dEi;
+    a.slab_cw = o.slab_cw; a.slab_cb = o.slab_cb; a.slab_dw = o.slab_dw; a.slab_db = o.slab_db; a.slab_stride = o.slab_stride;
+    a.B = B; a.F = o.g.F; a.K = o.g.K; a.P = o.g.P; a.act = o.g.act; a.loss = o.loss; a.invB = o.invB; a.L = 1.f;
+    if (o.g.K == 64) return launch_ibw<32>(a, nslab, stream);
+    if (o.g.K == 32) return launch_ibw<16>(a, nslab, stream);
+    return CFFM_ERR_UNSUPPORTED;
 }
