@@ -132,33 +132,6 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nphase = (a.B + E - 1) / E;
 
-    // ---- per-thread constants: its units' weights and LDS offsets ----------------------------------------------------
-    for (int i = tid; i < F; i += T) {
-        const int base = i * (2 * F - i - 1) / 2;
-        for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
-    }
-    for (int p = P + tid; p < NG * UPT; p += T) lut[p] = 0u;
-    const int g = tid / K2, t = tid - g * K2;
-    f32x2 w[UPT];
-    uint32_t off[UPT];                                       // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
-    const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
-#pragma unroll
-    for (int k = 0; k < UPT; ++k) {
-        const int p = g * UPT + k;
-        w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
-    }
-    const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
-    const float bd = a.bd[0];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < UPT; ++k) {
-        const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
-        off[k] = (uint32_t)(((int)(ij & 0xffff) * K + 2 * t) * 4) | ((uint32_t)(((int)(ij >> 16) * K + 2 * t) * 4) << 16);
-    }
-    // the unit loop forms LDS addresses as (offset | buffer << 16): dynamic LDS starts at address 0 in a kernel without
-    // static __shared__ variables
-    if ((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
-
     // ---- fetch role of this thread: piece q = tid of each of the E examples of a phase ------------------------------
     const bool fetch = tid < npiece;
     const bool is_in = tid < F * K4;
@@ -223,13 +196,43 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
         }
     };
 
-    int ph = blockIdx.x;
-    if (ph < nphase) {
-        if (fetch) load_ids(ph);
+    // the ids of this workgroup's first phase are requested before anything else: the weights / offsets set-up below runs in
+    // the shadow of that load, and the rows of the first phase follow right behind it
+    if ((int)blockIdx.x < nphase) {
+        if (fetch) load_ids(blockIdx.x);
         load_rows(0);
-        if (ph + (int)gridDim.x < nphase && fetch) load_ids(ph + gridDim.x);
-        row_sums(0, ph);
+        if ((int)(blockIdx.x + gridDim.x) < nphase && fetch) load_ids(blockIdx.x + gridDim.x);
     }
+
+    // ---- per-thread constants: its units' weights and LDS offsets ----------------------------------------------------
+    for (int i = tid; i < F; i += T) {
+        const int base = i * (2 * F - i - 1) / 2;
+        for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
+    }
+    for (int p = P + tid; p < NG * UPT; p += T) lut[p] = 0u;
+    const int g = tid / K2, t = tid - g * K2;
+    f32x2 w[UPT];
+    uint32_t off[UPT];                                       // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
+    const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const int p = g * UPT + k;
+        w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
+    }
+    const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
+    const float bd = a.bd[0];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
+        off[k] = (uint32_t)(((int)(ij & 0xffff) * K + 2 * t) * 4) | ((uint32_t)(((int)(ij >> 16) * K + 2 * t) * 4) << 16);
+    }
+    // the unit loop forms LDS addresses as (offset | buffer << 16): dynamic LDS starts at address 0 in a kernel without
+    // static __shared__ variables
+    if ((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+
+    int ph = blockIdx.x;
+    if (ph < nphase) row_sums(0, ph);
     __syncthreads();
     int par = 0;
     for (; ph < nphase; ph += gridDim.x, par ^= 1) {
