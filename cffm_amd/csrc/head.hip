@@ -10,7 +10,7 @@
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    head_fwd_body(a, blockIdx.x, smem);
+    head_fwd_body<4, -1, true>(a, blockIdx.x, smem);
 }
 
 // deterministic single-workgroup sum of n floats -> dst[0] (and dst[3] when mirror != 0)

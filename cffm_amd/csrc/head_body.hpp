@@ -41,7 +41,10 @@ static inline size_t head_fwd_lds(const Geo& g) { return (size_t)(1024 + 8 * CFF
 // first 256 threads (8 parts x 32 units)
 // CL (fused forward): LDS copies of this example's conv outputs (at fused_c_off(l, c0_off, c1_off, ..) inside smem) are read
 // instead of the global ones
-template <int NW = 4, int ACTC = -1>
+// POOLS: the stand-alone head of the wide shapes takes s0 and the layer pools as left by earlier kernels (s0_ready, pool[]).  The
+// fused forward instantiates POOLS = false: a.pool[l] / a.pool_np[l] with a run-time l would be a dynamically indexed member of a
+// by-value kernel argument, i.e. a private copy in scratch memory inside the single-launch forward (it cost fwd_all 1.4 us).
+template <int NW = 4, int ACTC = -1, bool POOLS = false>
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* smem, bool CL = false, int c0_off = 0, int c1_off = 0) {
     const int act = ACTC >= 0 ? ACTC : a.g.act;         // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int NTH = 64 * NW, RPW = 16 / NW;                    // rows per wave in one pooling sweep
@@ -91,12 +94,12 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
             yv = a.y ? a.y[b] : 0.f;
         }
     }
-    if (a.outer_conv && !a.s0_ready) {
+    if (a.outer_conv && !(POOLS && a.s0_ready)) {
         const float4* E4 = reinterpret_cast<const float4*>(a.Eo + (int64_t)b * g.F * g.D);
         for (int i = tid; i < g.F * g.D / 4; i += NTH) reinterpret_cast<float4*>(Et)[i] = E4[i];
     }
     float s0v = 0.f;                                                 // s0_ready: this thread's element of the pool, requested now
-    if (a.outer_conv && a.s0_ready && tid < g.D) s0v = a.t1[(int64_t)b * t1w + tid];
+    if (POOLS && a.outer_conv && a.s0_ready && tid < g.D) s0v = a.t1[(int64_t)b * t1w + tid];
     if (wave == FO) {                                                // first-order term, :422-446 (needs nothing from the other waves)
         float lin;
         if (g.linear_att) {
@@ -124,7 +127,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         int off = g.D;
         for (int l = 0; l < g.live; ++l) {                          // only s_1 .. s_{Lc-1} reach t1 (:394-396)
             const int S = g.D >> (l + 1);
-            if (!CL && a.pool_np[l] > 0) {                          // the conv epilogue left the partials: add them up in index order
+            if (POOLS && !CL && a.pool_np[l] > 0) {                 // the conv epilogue left the partials: add them up in index order
                 const int np = a.pool_np[l];
                 for (int y = tid; y < S; y += NTH) {
                     const float* pp = a.pool[l] + ((int64_t)b * S + y) * np;
@@ -164,7 +167,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, int b, char* sm
         PHASE_MARK3(2);
         lds_barrier();                                             // Et (and the pools) are in LDS
         PHASE_MARK3(3);
-        if (a.s0_ready) {                                            // kernel-uniform: every thread takes the same side
+        if (POOLS && a.s0_ready) {                                   // kernel-uniform: every thread takes the same side
             if (tid < g.D) t1s[tid] = s0v;                           // (g.D <= 256 <= NTH on this path: the tiled layer 0 has D <= 64)
         } else {
         for (int f = wave; f < g.F; f += NW) {                      // row sums of the embedding tile
