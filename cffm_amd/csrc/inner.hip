@@ -129,6 +129,8 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     float* RS = reinterpret_cast<float*>(smem + 2 * buf_bytes);   // [2][E][32] row sums of the outer rows
     float* red = RS + 2 * E * 32;                            // [2][16 waves][E] inner_out partials
     uint32_t* lut = reinterpret_cast<uint32_t*>(red + 2 * 16 * E);   // [NG * UPT] pair -> (i | j << 16)
+    float* fbL = reinterpret_cast<float*>(lut + NG * UPT);           // [2][128] feature_bias of the slots of a phase (landing zone of the DMA)
+    int* idsL = reinterpret_cast<int*>(fbL + 2 * 128);               // [2][128] raw ids of the slots of a phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nphase = (a.B + E - 1) / E;
 
@@ -139,49 +141,51 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     const int cq = is_in ? tid - fq * K4 : (tid - F * K4) - fq * D4;      // 16-byte piece inside the row
     const float* tbl = is_in ? a.inner : a.outer;
     const int rowlen4 = is_in ? K4 : D4;
-    // first-order role (:422): the thread that fetches the FIRST piece of an inner row also fetches feature_bias of that id and
-    // writes ws.fb / the sort key of the slot - with the id it already holds, so no dependent load sits in a phase
-    const bool fo_on = fetch && is_in && cq == 0;
+    // The ids of a phase travel through LDS as well: thread tid < E*F owns slot (e, f) = (tid / F, tid % F) and fetches its id by a
+    // 4-byte global_load_lds one phase before the rows that need it are requested; the fetch threads read the ids of their four
+    // rows from there.  No id, no feature_bias value and no pointer to them is held in a register across the unit loop: with
+    // them the kernel spilled, and a spill reload is a vector-memory operation - its vmcnt wait also waits for every row DMA
+    // issued before it, i.e. the waves that reloaded at the top of a phase sat out the whole HBM latency of their rows there and
+    // the rest of the workgroup waited for them at the phase barrier.
+    const bool fo_on = tid < E * F;                                        // first-order role (:422) + id fetch: waves 0 .. E*F/64 - 1
+    const int fo_e = fo_on ? tid / F : 0, fo_f = fo_on ? tid - fo_e * F : 0;
     const bool wave_has_outer = (wave + 1) * 64 > F * K4 && wave * 64 < npiece;      // some lane of this wave fetches an outer piece
-    int idn[E];                                                           // ids of the phase whose rows are fetched next
-    auto load_ids = [&](int ph) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int b = ph * E + e;
+    auto clampid = [&](int id) { return id < 0 ? 0 : (id >= a.M ? a.M - 1 : id); };   // a bad id must not fault the GPU
+    auto load_ids = [&](int ph, int ib) {                                  // ids of phase ph -> idsL[ib]
+        if (fo_on) {
+            int b = ph * E + fo_e;
             b = b < a.B ? b : a.B - 1;                                     // tail: a harmless duplicate
-            idn[e] = a.ids[(int64_t)b * F + fq];                           // raw: clamped where an address is formed
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.ids + (int64_t)b * F + fo_f),
+                                             (void __attribute__((address_space(3)))*)(idsL + ib * 128 + wave * 64), 4, 0, 0);
         }
     };
-    auto clampid = [&](int id) { return id < 0 ? 0 : (id >= a.M ? a.M - 1 : id); };   // a bad id must not fault the GPU
-    float fbn[E];                                                          // feature_bias of the phase being fetched (fo_on threads)
-    int rawn[E];
     // rows go HBM -> LDS directly (global_load_lds_dwordx4: the wave's 64 pieces land as 1 KB at a wave-uniform LDS base +
     // 16 * lane, which IS the image layout), so no staging registers are held across the compute phase
-    auto load_rows = [&](int buf) {
+    auto load_rows = [&](int buf, int ib) {                                // rows (and feature_bias) of the phase whose ids are in idsL[ib]
         if (fetch) {
+            int idv[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) idv[e] = idsL[ib * 128 + e * F + fq];
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 __builtin_amdgcn_global_load_lds(
-                    (const void __attribute__((address_space(1)))*)(reinterpret_cast<const f32x4*>(tbl) + (int64_t)clampid(idn[e]) * rowlen4 + cq),
+                    (const void __attribute__((address_space(1)))*)(reinterpret_cast<const f32x4*>(tbl) + (int64_t)clampid(idv[e]) * rowlen4 + cq),
                     (void __attribute__((address_space(3)))*)(rows + buf * buf_bytes + e * slot_bytes + wave * 1024), 16, 0, 0);
         }
-        if (fo_on) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) { rawn[e] = idn[e]; fbn[e] = a.fbias[clampid(idn[e])]; }
-        }
+        if (fo_on)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.fbias + clampid(idsL[ib * 128 + tid])),
+                                             (void __attribute__((address_space(3)))*)(fbL + buf * 128 + wave * 64), 4, 0, 0);
     };
     // once the wave's own loads have landed (vmcnt(0)): row sums of the outer rows for the s0 pool - D4 lanes hold one row
-    auto row_sums = [&](int buf, int phn) {
+    auto row_sums = [&](int buf, int phn, int ib) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (fo_on) {                                                       // first-order inputs + sort keys of phase phn
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int b = phn * E + e;
-                if (b < a.B) {
-                    const int64_t slot = (int64_t)b * F + fq;
-                    a.fb[slot] = fbn[e];
-                    if (a.keys) a.keys[slot] = ((unsigned long long)(unsigned)((rawn[e] < 0 || rawn[e] >= a.M) ? a.M : rawn[e]) << 32) | (unsigned long long)slot;   // bad id -> key M
-                }
+            const int b = phn * E + fo_e;
+            if (b < a.B) {
+                const int64_t slot = (int64_t)b * F + fo_f;
+                const int raw = idsL[ib * 128 + tid];
+                a.fb[slot] = fbL[buf * 128 + tid];                         // this wave's own DMA: visible behind the vmcnt(0) above
+                if (a.keys) a.keys[slot] = ((unsigned long long)(unsigned)((raw < 0 || raw >= a.M) ? a.M : raw) << 32) | (unsigned long long)slot;   // bad id -> key M
             }
         }
         if (wave_has_outer) {                                              // wave-uniform: the waves that hold only inner pieces skip
@@ -196,13 +200,8 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
         }
     };
 
-    // the ids of this workgroup's first phase are requested before anything else: the weights / offsets set-up below runs in
-    // the shadow of that load, and the rows of the first phase follow right behind it
-    if ((int)blockIdx.x < nphase) {
-        if (fetch) load_ids(blockIdx.x);
-        load_rows(0);
-        if ((int)(blockIdx.x + gridDim.x) < nphase && fetch) load_ids(blockIdx.x + gridDim.x);
-    }
+    // the ids of this workgroup's first phase are requested before anything else (the pair table below is built in their shadow)
+    if ((int)blockIdx.x < nphase) load_ids(blockIdx.x, 0);
 
     // ---- per-thread constants: its units' weights and LDS offsets ----------------------------------------------------
     for (int i = tid; i < F; i += T) {
@@ -221,7 +220,12 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     }
     const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
     const float bd = a.bd[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first phase's ids (and the weights above) have landed
     __syncthreads();
+    if ((int)blockIdx.x < nphase) {                                       // rows of the first phase, ids of the second
+        load_rows(0, 0);
+        if ((int)(blockIdx.x + gridDim.x) < nphase) load_ids(blockIdx.x + gridDim.x, 1);
+    }
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
         const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
@@ -232,15 +236,15 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     if ((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
 
     int ph = blockIdx.x;
-    if (ph < nphase) row_sums(0, ph);
+    if (ph < nphase) row_sums(0, ph, 0);
     __syncthreads();
-    int par = 0;
+    int par = 0;                                               // phase ph: rows in rows[par], ids in idsL[par]
     for (; ph < nphase; ph += gridDim.x, par ^= 1) {
         const int nxt = ph + gridDim.x;
         const bool more = nxt < nphase;
         if (more) {
-            load_rows(par ^ 1);                                            // next phase's rows: in flight across the compute below
-            if (nxt + (int)gridDim.x < nphase && fetch) load_ids(nxt + gridDim.x);
+            load_rows(par ^ 1, par ^ 1);                                   // next phase's rows: in flight across the compute below
+            if (nxt + (int)gridDim.x < nphase) load_ids(nxt + gridDim.x, par);   // idsL[par] (this phase's ids) is free: its keys are out
         }
         // ---- inner branch of the E examples of this phase ------------------------------------------------------------
         const char* buf = rows + par * buf_bytes;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
             for (; i >= 0; --i) { R += rs[i + 1]; s += Eo[i * D + hh] * R; }
             if (h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
         }
-        if (more) row_sums(par ^ 1, nxt);                                  // waits for the rows that were in flight
+        if (more) row_sums(par ^ 1, nxt, par ^ 1);                                  // waits for the rows that were in flight
         __syncthreads();
         if (tid < E) {                                                     // inner_out of this phase: wavefront partials in wave order
             const int b = ph * E + tid;
@@ -374,12 +378,12 @@ int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, 
     const int K2 = g.K / 2, NG = GIW_T / K2;
     const int upt = (g.P + NG - 1) / NG;                       // pairs per thread group
     const int npiece = g.F * (g.K / 4 + g.D / 4);
-    if (npiece > GIW_T || g.D > 64 || g.F > 32 || GIW_E * 256 != GIW_T) return CFFM_ERR_UNSUPPORTED;
+    if (npiece > GIW_T || g.D > 64 || g.F > 32 || GIW_E * 256 != GIW_T || GIW_E * g.F > 128) return CFFM_ERR_UNSUPPORTED;
     const int nphase = (B + GIW_E - 1) / GIW_E;
     int grid = nphase < 256 ? nphase : 256;                    // one workgroup per CU, phases dealt round-robin
     int uptT = upt <= 4 ? 4 : (upt <= 8 ? 8 : 16);
     if (upt > 16) return CFFM_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)2 * 65536 + (size_t)(2 * GIW_E * 32 + 2 * 16 * GIW_E + NG * uptT) * 4;
+    const size_t lds = (size_t)2 * 65536 + (size_t)(2 * GIW_E * 32 + 2 * 16 * GIW_E + NG * uptT + 4 * 128) * 4;
     if (K2 == 32) {
         if (uptT == 4) return launch_giw<32, 4>(a, grid, lds, stream);
         if (uptT == 8) return launch_giw<32, 8>(a, grid, lds, stream);
