@@ -98,6 +98,10 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
             out->pool_np[l] = np;
             if (np > 0) out->pool[l] = take(b * (g.D >> (l + 1)) * np * 4);
         }
+        if (conv0_tile_dgrad2_ok(g)) {                           // WA + WE of conv0_fact_tile_dgrad2_kernel (conv.hip)
+            out->w0pack_floats = 2 * (int64_t)(2 * g.F) * (g.Pp / 16) * 1024;
+            out->w0pack = take(out->w0pack_floats * 4);
+        }
     }
     out->bytes = o;
     return 0;

@@ -85,6 +85,8 @@ static inline bool conv0_fact_tile_ok(const Geo& g) {
     const int S = g.D / 2;
     return g.Pp > 64 && S >= 16 && S % 16 == 0 && 2 * (g.F - 1) <= 4 * C0T_MAXKS;
 }
+// the tiled layer-0 input gradient that reads the filter as pre-packed MFMA fragments (ws.w0pack)
+static inline bool conv0_tile_dgrad2_ok(const Geo& g) { return conv0_fact_tile_ok(g) && g.D / 2 <= 32 && g.F <= 32; }
 static inline bool conv0_tile_fwd_ok(const Geo& g) { return conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS; }
 // column tiles of 16 -> column blocks of NT tiles (NT in {1,2,3,4,6,8}) of the implicit-GEMM kernels
 static inline void pick_nt(int tiles, int* nblk, int* NT) {

@@ -3203,7 +3203,323 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
 }
 
 #undef CFFM_TILE_FETCH
-static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st) {
+
+// ---- the same input gradient with the filter read as PRE-PACKED MFMA fragments ------------------------------------------
+// rocprofv3 + the ISA of the kernel above: 19.7 K instructions for 784 MFMAs - per MFMA of phases A and E a dozen integer
+// instructions of (pair, tap) address arithmetic, two selects and a 64-bit multiply-add, unrolled over 4 row groups x 2 column
+// tiles (an instruction stream larger than the instruction cache); MFMA pipe busy 30 %.  Here the layer-0 filter is laid out
+// ONCE per backward pass (pack_w0_tile_kernel, 16 MB written, a few us) exactly as the two phases consume it:
+//   WA[m = (dh,i)][qt][ks = dw*8 + c][lane = (kk,r)]      = W[dh,dw,(i,j),q0+r],  j = 4c + kk  (0 where j <= i or j >= F)
+//   WE[m = (dh,i)][qt][t][lane = (kk,r)] (16 bytes)       = W[dh,dw,(i,j),q0+4kk .. +3],  row n = 16t + r = dw*F + j  (0 likewise)
+// so a fragment is ONE load at (wave-uniform base) + lane with no select, k of phase A runs over ALL fields (the E operand of
+// a k-step no longer depends on the unit: one LDS read pair feeds the wave's UPW units) and the k-steps whose fields all lie
+// at or below i are skipped (8.5 MFMAs per unit on average instead of 12).
+__global__ __launch_bounds__(256) void pack_w0_tile_kernel(const float* __restrict__ W, float* __restrict__ WA, float4* __restrict__ WE,
+                                                          int F, int Pp) {
+    const int QT = Pp / 16, m = blockIdx.x / QT, qt = blockIdx.x - m * QT, q0 = qt * 16;
+    const int dh = m >= F ? 1 : 0, i = m - dh * F, base = i * (2 * F - i - 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
+    float* wa = WA + (int64_t)blockIdx.x * 1024;
+    for (int e = tid; e < 1024; e += 256) {
+        const int ks = e >> 6, dw = ks >> 3, j = 4 * (ks & 7) + kk;
+        const bool ok = j < F && j > i;
+        wa[e] = ok ? W[((int64_t)(dh * 2 + dw) * Pp + base + (j - i - 1)) * Pp + q0 + r] : 0.f;
+    }
+    {
+        const int t = tid >> 6, n = t * 16 + r, dw = n >= F ? 1 : 0, j = n - dw * F;
+        const bool ok = n < 2 * F && j > i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(W + ((int64_t)(dh * 2 + dw) * Pp + base + (j - i - 1)) * Pp + q0 + 4 * kk);
+        WE[(int64_t)blockIdx.x * 256 + tid] = v;
+    }
+}
+
+template <int SMAX, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(DgradArgs a, const float* __restrict__ WA,
+                                                                           const float4* __restrict__ WE) {
+    constexpr int NTH = 64 * NW, UPW = 16 / NW, KPW = 64 / NW, NX = SMAX * 64 / NTH;
+    static_assert(NX == 8 || NX == 4, "named prefetch registers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, YT = S / 16, PpT = a.Pp, QT = PpT / 16, G = (2 * F + 15) / 16;
+    const int CE = (F + 3) / 4, Fp = 4 * CE, NTE = (2 * F + 15) / 16;
+    constexpr int TGP = 258, DCP = 260;
+    float* Es = reinterpret_cast<float*>(smem);                // [Fp][Dp], rows F.. zero
+    float* dCt = Es + (Fp * Dp + 3) / 4 * 4;                   // [S][DCP]: (x, q) at x*16 + q
+    float* Tg = dCt + SMAX * DCP;                               // [16 m][TGP]
+    float* dTg = Tg + 16 * TGP;                                 // [16 m][16 x][16 q]
+    static_assert(NW * 4 * 256 <= 16 * TGP + 4096, "the cross-wave partial sums reuse Tg (and dTg)");
+    static_assert(2 * 64 * SMAX + 128 <= SMAX * DCP, "the epilogue outputs reuse dCt");
+    float* part = Tg;                                           // [NW waves][4 tiles][64 lanes][4]   cross-wave sums (epilogue)
+    float* dEi = dCt;                                           // [G*16][SMAX]    (n = dh*F + i, y)            (epilogue)
+    float* dEj = dEi + 64 * SMAX;                               // [64][SMAX]      (n = dw*F + j, x)            (epilogue)
+    float* rs = dEj + 64 * SMAX;                                // [F] row sums, [F] dots
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.x;
+    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
+    for (int e = tid; e < (Fp - F) * Dp; e += NTH) Es[F * Dp + e] = 0.f;
+    f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accE[xt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accB[4][2];                                          // [row group g][y tile] x (16 rows of the group)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int yt = 0; yt < 2; ++yt) accB[g][yt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* dCb = a.dC + (int64_t)b * S * S * PpT;
+    float4 nx0, nx1, nx2, nx3, nx4, nx5, nx6, nx7;             // the NEXT dC tile (named: an array ends up in scratch memory here)
+    nx4 = nx5 = nx6 = nx7 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define CFFM_TILE_FETCH2(X0N, Q0N)                                                                                             \
+    do {                                                                                                                      \
+        const float* tb_ = dCb + (int64_t)(X0N) * PpT + (Q0N) + 4 * (tid & 3) + (int64_t)((tid >> 2) & 15) * PpT;              \
+        const int64_t ys_ = (int64_t)S * PpT;                  /* piece u of this thread: y = (tid >> 6) + NW*u */             \
+        const int y_ = tid >> 6;                                                                                              \
+        nx0 = *reinterpret_cast<const float4*>(tb_ + min(y_, S - 1) * ys_);                                                   \
+        nx1 = *reinterpret_cast<const float4*>(tb_ + min(y_ + NW, S - 1) * ys_);                                              \
+        nx2 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 2 * NW, S - 1) * ys_);                                          \
+        nx3 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 3 * NW, S - 1) * ys_);                                          \
+        if constexpr (NX > 4) {                                                                                               \
+            nx4 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 4 * NW, S - 1) * ys_);                                      \
+            nx5 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 5 * NW, S - 1) * ys_);                                      \
+            nx6 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 6 * NW, S - 1) * ys_);                                      \
+            nx7 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 7 * NW, S - 1) * ys_);                                      \
+        }                                                                                                                     \
+    } while (0)
+    CFFM_TILE_FETCH2(0, 0);
+    // xt and g are RUN-TIME loops (one copy of phases A and C in the instruction stream); the accumulators that live across
+    // the walk are picked by a switch around phases B and E only
+#pragma clang loop unroll(disable)
+    for (int xt = 0; xt < RT; ++xt) {
+        const int x0 = xt * 16;
+        const float* eb = Es + kk * Dp + 2 * (x0 + r);        // phase A: E operand of k-step c, tap dw: eb[4*c*Dp + dw]
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q0 = qt * 16;
+            __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
+            {                                                  // the dC tile is staged ONCE for the four row groups
+                float* tl_ = dCt + ((tid >> 2) & 15) * 16 + 4 * (tid & 3);
+                const int y_ = tid >> 6;
+                if (y_ < S) *reinterpret_cast<float4*>(tl_ + y_ * DCP) = nx0;
+                if (y_ + NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + NW) * DCP) = nx1;
+                if (y_ + 2 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 2 * NW) * DCP) = nx2;
+                if (y_ + 3 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 3 * NW) * DCP) = nx3;
+                if constexpr (NX > 4) {
+                    if (y_ + 4 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 4 * NW) * DCP) = nx4;
+                    if (y_ + 5 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 5 * NW) * DCP) = nx5;
+                    if (y_ + 6 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 6 * NW) * DCP) = nx6;
+                    if (y_ + 7 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 7 * NW) * DCP) = nx7;
+                }
+            }
+            {   // the next tile (clamped to the last one: a harmless re-read at the very end)
+                const bool nq = qt + 1 < QT, nxt = xt + 1 < RT;
+                CFFM_TILE_FETCH2(nq ? x0 : (nxt ? x0 + 16 : x0), nq ? q0 + 16 : (nxt ? 0 : q0));
+            }
+#pragma clang loop unroll(disable)
+            for (int g = 0; g < G; ++g) {
+                const int mC = g * 16 + r;                      // phase C row of this lane
+                const bool mC_ok = mC < 2 * F;
+                const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+                // the wave's UPW units of this group (wave-uniform): m = (dh, i), first useful k-step, fragment bases
+                int mU[UPW], iU[UPW];
+                bool okU[UPW];
+                int cs = CE;
+#pragma clang loop unroll(full)
+                for (int u = 0; u < UPW; ++u) {
+                    const int m = g * 16 + wave * UPW + u;
+                    okU[u] = m < 2 * F;
+                    mU[u] = min(m, 2 * F - 1);
+                    iU[u] = mU[u] - (mU[u] >= F ? F : 0);
+                    cs = min(cs, (iU[u] + 1) >> 2);
+                }
+                if (g > 0) __syncthreads();                    // Tg / dTg of the previous group consumed
+                // ---- A: T planes of this wave's units: rows x, K = (dw, j) over all fields from k-step cs on, cols q ---------
+                {
+                    f32x4 acc[UPW];
+                    const float* wa[UPW];
+#pragma clang loop unroll(full)
+                    for (int u = 0; u < UPW; ++u) {
+                        acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        wa[u] = WA + ((int64_t)mU[u] * QT + qt) * 1024 + lane;
+                    }
+                    if (cs < CE) {
+                        int c = cs;
+                        float e0 = eb[4 * c * Dp], e1 = eb[4 * c * Dp + 1], w0[UPW], w1[UPW];
+#pragma clang loop unroll(full)
+                        for (int u = 0; u < UPW; ++u) { w0[u] = wa[u][c * 64]; w1[u] = wa[u][(c + 8) * 64]; }
+                        while (true) {
+                            const int cn = c + 1;
+                            const bool more = cn < CE;
+                            float ne0 = 0.f, ne1 = 0.f, nw0[UPW], nw1[UPW];
+                            if (more) {
+                                ne0 = eb[4 * cn * Dp]; ne1 = eb[4 * cn * Dp + 1];
+#pragma clang loop unroll(full)
+                                for (int u = 0; u < UPW; ++u) { nw0[u] = wa[u][cn * 64]; nw1[u] = wa[u][(cn + 8) * 64]; }
+                            }
+#pragma clang loop unroll(full)
+                            for (int u = 0; u < UPW; ++u) {
+                                acc[u] = mfma16(e0, w0[u], acc[u]);
+                                acc[u] = mfma16(e1, w1[u], acc[u]);
+                            }
+                            if (!more) break;
+                            e0 = ne0; e1 = ne1; c = cn;
+#pragma clang loop unroll(full)
+                            for (int u = 0; u < UPW; ++u) { w0[u] = nw0[u]; w1[u] = nw1[u]; }
+                        }
+                    }
+#pragma clang loop unroll(full)
+                    for (int u = 0; u < UPW; ++u) {
+                        const int ml = wave * UPW + u;
+                        if (!okU[u]) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Tg[ml * TGP + (kk * 4 + j) * 16 + r] = acc[u][j];
+                    }
+                }
+                if (g == 0) __syncthreads();                   // dCt staged
+                // ---- C: dT planes of the group, wave's columns UPW*wave .. UPW*wave + UPW-1 ---------------------------------
+                {
+                    f32x4 acc[UPW];
+#pragma clang loop unroll(full)
+                    for (int xl = 0; xl < UPW; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int s4 = 0; s4 < S / 4; ++s4) {
+                        const int y = 4 * s4 + kk;
+                        const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
+#pragma clang loop unroll(full)
+                        for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[y * DCP + (UPW * wave + xl) * 16 + r], acc[xl]);
+                    }
+#pragma clang loop unroll(full)
+                    for (int xl = 0; xl < UPW; ++xl)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wave + xl) * 16 + r] = acc[xl][j];
+                }
+                // the filter fragments of phase E are requested here: phase B hides their latency
+                float4 we[UPW][4];
+                unsigned emask[UPW];
+#pragma clang loop unroll(full)
+                for (int u = 0; u < UPW; ++u) {
+                    const float4* wep = WE + (((int64_t)mU[u] * QT + qt) * 4) * 64 + lane;
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        // tile t holds rows n = 16t .. 16t+15 of (dw*F + j): empty when none of them has j > i
+                        const int lo_max = min(F - 1, t * 16 + 15), hi_max = min(2 * F - 1, t * 16 + 15) - F;
+                        const bool any = okU[u] && t < NTE && ((t * 16 < F && lo_max > iU[u]) || (t * 16 + 15 >= F && hi_max > iU[u]));
+                        if (any) { mk |= 1u << t; we[u][t] = wep[t * 64]; }
+                    }
+                    emask[u] = mk;
+                }
+                __syncthreads();                               // Tg and dTg written
+                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, KPW per wave), cols m -------------------
+#define CFFM_PHASE_B(GG)                                                                                                      \
+    for (int ks = 0; ks < KPW; ++ks) {                                                                                        \
+        const int kf = 4 * (wave * KPW + ks) + kk, x = kf >> 4, q = kf & 15;                                                  \
+        const float bv = Tg[r * TGP + x * 16 + q];                                                                            \
+        accB[GG][0] = mfma16(dCt[r * DCP + x * 16 + q], bv, accB[GG][0]);                                                     \
+        if (YT > 1) accB[GG][1] = mfma16(dCt[(16 + r) * DCP + x * 16 + q], bv, accB[GG][1]);                                  \
+    }
+                switch (g) {
+                    case 0: CFFM_PHASE_B(0) break;
+                    case 1: CFFM_PHASE_B(1) break;
+                    case 2: CFFM_PHASE_B(2) break;
+                    default: CFFM_PHASE_B(3) break;
+                }
+#undef CFFM_PHASE_B
+                // ---- E: dEj rows (dw,j), K = q, cols x: this wave's units ------------------------------------------------------
+#define CFFM_PHASE_E(XT)                                                                                                      \
+    _Pragma("clang loop unroll(full)") for (int u = 0; u < UPW; ++u) {                                                        \
+        if (emask[u] == 0) continue;                                                                                          \
+        const int ml = wave * UPW + u;                                                                                        \
+        const float4 bv = *reinterpret_cast<const float4*>(dTg + (ml * 16 + r) * 16 + 4 * kk);   /* [k = q = 4kk+c][n = x = r] */ \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                       \
+            if (!((emask[u] >> t) & 1u)) continue;                                                                            \
+            const float4 wv = we[u][t];                                                                                       \
+            accE[XT][t] = mfma16(wv.x, bv.x, accE[XT][t]);                                                                    \
+            accE[XT][t] = mfma16(wv.y, bv.y, accE[XT][t]);                                                                    \
+            accE[XT][t] = mfma16(wv.z, bv.z, accE[XT][t]);                                                                    \
+            accE[XT][t] = mfma16(wv.w, bv.w, accE[XT][t]);                                                                    \
+        }                                                                                                                     \
+    }
+                if (xt == 0) { CFFM_PHASE_E(0) } else { CFFM_PHASE_E(1) }
+#undef CFFM_PHASE_E
+            }
+        }
+    }
+#undef CFFM_TILE_FETCH2
+    // ---- dEi: sum the wavefronts' K slices, group by group ------------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g >= G) continue;
+        __syncthreads();
+#pragma unroll
+        for (int yt = 0; yt < 2; ++yt)
+            *reinterpret_cast<f32x4*>(part + ((wave * 4 + yt) * 64 + lane) * 4) = accB[g][yt];
+        __syncthreads();
+        for (int e = tid; e < YT * 256; e += NTH) {              // e = (yt, lane, j)
+            const int j = e & 3, ln = (e >> 2) & 63, yt = e >> 8;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[((w * 4 + yt) * 64 + ln) * 4 + j];
+            const int y = yt * 16 + (ln >> 4) * 4 + j, mm = g * 16 + (ln & 15);          // D layout: row y, col m
+            dEi[mm * SMAX + y] = v;
+        }
+    }
+    // ---- dEj: sum the wavefronts' unit subsets -----------------------------------------------------------------------
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+        if (xt >= RT) continue;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part + ((wave * 4 + t) * 64 + lane) * 4) = accE[xt][t];
+        __syncthreads();
+        for (int e = tid; e < 4 * 256; e += NTH) {              // e = (t, lane, j)
+            const int j = e & 3, ln = (e >> 2) & 63, t = e >> 8;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += part[((w * 4 + t) * 64 + ln) * 4 + j];
+            const int n = t * 16 + (ln >> 4) * 4 + j, x = xt * 16 + (ln & 15);           // D layout: row (dw,j), col x
+            dEj[n * SMAX + x] = v;
+        }
+    }
+    if (tid < 2 * F) {                                           // row sums and <ds0, E[f]> for the closed-form s0 terms
+        const int f = tid % F;
+        float sacc = 0.f;
+        if (tid < F) { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h]; }
+        else { for (int h = 0; h < D; ++h) sacc += Es[f * Dp + h] * a.dt1[(int64_t)b * a.t1w + h]; }
+        rs[tid] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < F * D; e += NTH) {
+        const int f = e / D, h = e - f * D, lo = h & 1, hh = h >> 1;
+        float R = 0.f, Q = 0.f;
+        for (int j = f + 1; j < F; ++j) R += rs[j];
+        for (int i = 0; i < f; ++i) Q += rs[F + i];
+        a.dprev[(int64_t)b * F * D + e] = (dEi[(lo * F + f) * SMAX + hh] + dEj[(lo * F + f) * SMAX + hh])
+                                          + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
+    }
+}
+
+template <int NW>
+static int launch_conv0_fact_tile_dgrad2(const DgradArgs& a, float* wpack, hipStream_t st) {
+    const int QT = a.Pp / 16, CE = (a.F + 3) / 4;
+    float* WA = wpack;
+    float4* WE = reinterpret_cast<float4*>(wpack + (int64_t)2 * a.F * QT * 1024);
+    hipLaunchKernelGGL(pack_w0_tile_kernel, dim3(2 * a.F * QT), dim3(256), 0, st, a.W, WA, WE, a.F, a.Pp);
+    CFFM_CHECK_LAUNCH();
+    // Es [4*CE][D+1] | dCt [32][260] | Tg [16][258] | dTg [4096]
+    const size_t lds = (size_t)((4 * CE * (a.D + 1) + 3) / 4 * 4 + 32 * 260 + 16 * 258 + 4096) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_dgrad2_kernel<32, NW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv0_fact_tile_dgrad2_kernel<32, NW>), dim3(a.B), dim3(64 * NW), lds, st, a, (const float*)WA, (const float4*)WE);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st, float* wpack = nullptr) {
+    const char* ver = getenv("CFFM_TILE_DGRAD");                // debug: 1 = the round-2 kernel, 8 = packed fragments with 8 wavefronts
+    if (wpack != nullptr && a.F <= 32 && a.D / 2 <= 32 && !(ver && ver[0] == '1')) {
+        if (ver && ver[0] == '8') return launch_conv0_fact_tile_dgrad2<8>(a, wpack, st);
+        return launch_conv0_fact_tile_dgrad2<4>(a, wpack, st);
+    }
+
     const int S = a.D / 2;
     if (S > 32 || 2 * a.F > 64) return CFFM_ERR_UNSUPPORTED;
     constexpr int NW = 4;                // measured at F32 D64 B8192: 118 ms with 4 wavefronts, 194 ms with 8 (register spills)
@@ -3643,7 +3959,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         }
         if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32 && 2 * g.F <= 64) {
             if (rs) { a.Cprev = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
-            return launch_conv0_fact_tile_dgrad(a, st);
+            return launch_conv0_fact_tile_dgrad(a, st, wl.w0pack_floats > 0 ? (float*)(w + wl.w0pack) : nullptr);
         }
         if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;
         pick_nt(4 * g.Pp / 16, &nblk, &NT);

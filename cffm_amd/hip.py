@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
@@ -49,7 +49,8 @@ class WsLayout(C.Structure):
                 ('dC', C.c_int64 * MAX_LAYERS), ('dEi', C.c_int64), ('dEo', C.c_int64), ('dfb', C.c_int64),
                 ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
                 ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64), ('Gfb', C.c_int64),
-                ('pool', C.c_int64 * MAX_LAYERS), ('pool_np', C.c_int32 * MAX_LAYERS)]
+                ('pool', C.c_int64 * MAX_LAYERS), ('pool_np', C.c_int32 * MAX_LAYERS),
+                ('w0pack', C.c_int64), ('w0pack_floats', C.c_int64)]
 
 
 class Tables(C.Structure):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 6
+#define CFFM_ABI_VERSION 7
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -104,6 +104,10 @@ typedef struct cffm_ws_layout {
     int64_t pool[CFFM_MAX_LAYERS];          /* wide shapes (Pp > 64): partial sum pools of act(C_l) left by the conv epilogues,
                                                [B][S_l][pool_np[l]] floats (0 = not used); the head adds the partials up       */
     int32_t pool_np[CFFM_MAX_LAYERS];       /* partials per (example, row y) of layer l                                          */
+    int64_t w0pack;                         /* wide shapes with the tiled layer 0: the layer-0 filter re-laid out as MFMA operand
+                                               fragments for the input-gradient kernel (rebuilt from theta by every backward pass;
+                                               0 = not used)                                                                        */
+    int64_t w0pack_floats;
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
