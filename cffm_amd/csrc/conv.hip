@@ -3237,14 +3237,13 @@ __global__ __launch_bounds__(256) void pack_w0_tile_kernel(const float* __restri
 template <int SMAX, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(DgradArgs a, const float* __restrict__ WA,
                                                                            const float4* __restrict__ WE) {
-    constexpr int NTH = 64 * NW, UPW = 16 / NW, KPW = 64 / NW, NX = SMAX * 64 / NTH;
-    static_assert(NX == 8 || NX == 4, "named prefetch registers");
+    constexpr int NTH = 64 * NW, UPW = 16 / NW, KPW = 64 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = a.F, D = a.D, S = D / 2, Dp = D + 1, RT = S / 16, YT = S / 16, PpT = a.Pp, QT = PpT / 16, G = (2 * F + 15) / 16;
     const int CE = (F + 3) / 4, Fp = 4 * CE, NTE = (2 * F + 15) / 16;
     constexpr int TGP = 258, DCP = 260;
-    float* Es = reinterpret_cast<float*>(smem);                // [Fp][Dp], rows F.. zero
-    float* dCt = Es + (Fp * Dp + 3) / 4 * 4;                   // [S][DCP]: (x, q) at x*16 + q
+    float* Es = reinterpret_cast<float*>(smem);                // [Fp + 1][Dp], rows F .. Fp zero (Fp: the row of lanes without a unit)
+    float* dCt = Es + ((Fp + 1) * Dp + 3) / 4 * 4;             // [S][DCP]: (x, q) at x*16 + q
     float* Tg = dCt + SMAX * DCP;                               // [16 m][TGP]
     float* dTg = Tg + 16 * TGP;                                 // [16 m][16 x][16 q]
     static_assert(NW * 4 * 256 <= 16 * TGP + 4096, "the cross-wave partial sums reuse Tg (and dTg)");
@@ -3255,8 +3254,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
     float* rs = dEj + 64 * SMAX;                                // [F] row sums, [F] dots
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x;
+    const unsigned ulane = lane;
     stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
-    for (int e = tid; e < (Fp - F) * Dp; e += NTH) Es[F * Dp + e] = 0.f;
+    for (int e = tid; e < (Fp + 1 - F) * Dp; e += NTH) Es[F * Dp + e] = 0.f;
     f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt)
@@ -3268,25 +3268,20 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt) accB[g][yt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* dCb = a.dC + (int64_t)b * S * S * PpT;
-    float4 nx0, nx1, nx2, nx3, nx4, nx5, nx6, nx7;             // the NEXT dC tile (named: an array ends up in scratch memory here)
-    nx4 = nx5 = nx6 = nx7 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define CFFM_TILE_FETCH2(X0N, Q0N)                                                                                             \
-    do {                                                                                                                      \
-        const float* tb_ = dCb + (int64_t)(X0N) * PpT + (Q0N) + 4 * (tid & 3) + (int64_t)((tid >> 2) & 15) * PpT;              \
-        const int64_t ys_ = (int64_t)S * PpT;                  /* piece u of this thread: y = (tid >> 6) + NW*u */             \
-        const int y_ = tid >> 6;                                                                                              \
-        nx0 = *reinterpret_cast<const float4*>(tb_ + min(y_, S - 1) * ys_);                                                   \
-        nx1 = *reinterpret_cast<const float4*>(tb_ + min(y_ + NW, S - 1) * ys_);                                              \
-        nx2 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 2 * NW, S - 1) * ys_);                                          \
-        nx3 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 3 * NW, S - 1) * ys_);                                          \
-        if constexpr (NX > 4) {                                                                                               \
-            nx4 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 4 * NW, S - 1) * ys_);                                      \
-            nx5 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 5 * NW, S - 1) * ys_);                                      \
-            nx6 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 6 * NW, S - 1) * ys_);                                      \
-            nx7 = *reinterpret_cast<const float4*>(tb_ + min(y_ + 7 * NW, S - 1) * ys_);                                      \
-        }                                                                                                                     \
-    } while (0)
-    CFFM_TILE_FETCH2(0, 0);
+    // The dC tile goes HBM -> LDS directly (global_load_lds_dwordx4: the 64 pieces of row y = (x, q4) land as 1 KB at
+    // dCt + y*DCP): no staging registers (eight float4s per lane, four of them spilled next to 96 accumulation registers).
+    // The tile of step n+1 is requested in the LAST row group of step n, once phase B has read dCt for the last time, and
+    // lands behind that group's phase E.  Rows beyond S are never read (clamped source, S = 16).
+    auto fetch_tile = [&](int x0n, int q0n) {
+        const float* src = dCb + (int64_t)(x0n + (lane >> 2)) * PpT + q0n + 4 * (lane & 3);
+#pragma unroll
+        for (int k = 0; k < SMAX / NW; ++k) {
+            const int y = wave + NW * k;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (int64_t)min(y, S - 1) * S * PpT),
+                                             (void __attribute__((address_space(3)))*)(dCt + y * DCP), 16, 0, 0);
+        }
+    };
+    fetch_tile(0, 0);
     // xt and g are RUN-TIME loops (one copy of phases A and C in the instruction stream); the accumulators that live across
     // the walk are picked by a switch around phases B and E only
 #pragma clang loop unroll(disable)
@@ -3295,126 +3290,147 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
         const float* eb = Es + kk * Dp + 2 * (x0 + r);        // phase A: E operand of k-step c, tap dw: eb[4*c*Dp + dw]
         for (int qt = 0; qt < QT; ++qt) {
             const int q0 = qt * 16;
-            __syncthreads();                                   // dCt / Tg / dTg of the previous step consumed
-            {                                                  // the dC tile is staged ONCE for the four row groups
-                float* tl_ = dCt + ((tid >> 2) & 15) * 16 + 4 * (tid & 3);
-                const int y_ = tid >> 6;
-                if (y_ < S) *reinterpret_cast<float4*>(tl_ + y_ * DCP) = nx0;
-                if (y_ + NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + NW) * DCP) = nx1;
-                if (y_ + 2 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 2 * NW) * DCP) = nx2;
-                if (y_ + 3 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 3 * NW) * DCP) = nx3;
-                if constexpr (NX > 4) {
-                    if (y_ + 4 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 4 * NW) * DCP) = nx4;
-                    if (y_ + 5 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 5 * NW) * DCP) = nx5;
-                    if (y_ + 6 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 6 * NW) * DCP) = nx6;
-                    if (y_ + 7 * NW < S) *reinterpret_cast<float4*>(tl_ + (y_ + 7 * NW) * DCP) = nx7;
-                }
-            }
-            {   // the next tile (clamped to the last one: a harmless re-read at the very end)
-                const bool nq = qt + 1 < QT, nxt = xt + 1 < RT;
-                CFFM_TILE_FETCH2(nq ? x0 : (nxt ? x0 + 16 : x0), nq ? q0 + 16 : (nxt ? 0 : q0));
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the tile have landed
+            __syncthreads();                                   // ... and everybody's; Tg / dTg of the previous step consumed
 #pragma clang loop unroll(disable)
             for (int g = 0; g < G; ++g) {
-                const int mC = g * 16 + r;                      // phase C row of this lane
-                const bool mC_ok = mC < 2 * F;
-                const int dhC = mC_ok && mC >= F ? 1 : 0, iC = mC_ok ? mC - dhC * F : 0;
+                const int mC = g * 16 + r;                      // phase C row of this lane (a row beyond 2F reads the zero row of Es)
+                const int dhC = (mC < 2 * F && mC >= F) ? 1 : 0, iC = mC < 2 * F ? mC - dhC * F : Fp;
                 // the wave's UPW units of this group (wave-uniform): m = (dh, i), first useful k-step, fragment bases
-                int mU[UPW], iU[UPW];
-                bool okU[UPW];
+                int mU[UPW], iU[UPW], okU[UPW];
                 int cs = CE;
 #pragma clang loop unroll(full)
                 for (int u = 0; u < UPW; ++u) {
                     const int m = g * 16 + wave * UPW + u;
-                    okU[u] = m < 2 * F;
+                    okU[u] = m < 2 * F ? 1 : 0;
                     mU[u] = min(m, 2 * F - 1);
                     iU[u] = mU[u] - (mU[u] >= F ? F : 0);
                     cs = min(cs, (iU[u] + 1) >> 2);
                 }
+                cs = __builtin_amdgcn_readfirstlane(cs);       // (hipcc takes the minimum in a vector register: keep the fragment
+                                                               //  addresses below scalar base + lane)
+                // ---- A: T planes of this wave's units: rows x, K = (dw, j) over all fields from k-step cs on, cols q; the first
+                //         DEPTH k-steps are requested before the barrier (they depend on (unit, qt) only), then k-step d + DEPTH
+                //         is requested when k-step d is multiplied
+                f32x4 accA[UPW];
+                constexpr int DEPTH = 3;
+                float wv0[DEPTH][UPW], wv1[DEPTH][UPW], ev0[DEPTH], ev1[DEPTH];
+                const float* wa[UPW];
+#pragma clang loop unroll(full)
+                for (int u = 0; u < UPW; ++u) {
+                    accA[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    wa[u] = WA + __builtin_amdgcn_readfirstlane((mU[u] * QT + qt) * 1024);   // wave-uniform: fragment = (scalar base)[lane]
+                }
+#define CFFM_A_REQ(SLOT, C)                                                                                                   \
+    if ((C) < CE) {                                                                                                           \
+        _Pragma("clang loop unroll(full)") for (int u = 0; u < UPW; ++u) {                                                    \
+            wv0[SLOT][u] = (wa[u] + (C) * 64)[ulane]; wv1[SLOT][u] = (wa[u] + ((C) + 8) * 64)[ulane];                                             \
+        }                                                                                                                     \
+        ev0[SLOT] = eb[4 * (C) * Dp]; ev1[SLOT] = eb[4 * (C) * Dp + 1];                                                       \
+    }
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) { CFFM_A_REQ(d, cs + d) }
                 if (g > 0) __syncthreads();                    // Tg / dTg of the previous group consumed
-                // ---- A: T planes of this wave's units: rows x, K = (dw, j) over all fields from k-step cs on, cols q ---------
-                {
-                    f32x4 acc[UPW];
-                    const float* wa[UPW];
-#pragma clang loop unroll(full)
-                    for (int u = 0; u < UPW; ++u) {
-                        acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        wa[u] = WA + ((int64_t)mU[u] * QT + qt) * 1024 + lane;
-                    }
-                    if (cs < CE) {
-                        int c = cs;
-                        float e0 = eb[4 * c * Dp], e1 = eb[4 * c * Dp + 1], w0[UPW], w1[UPW];
-#pragma clang loop unroll(full)
-                        for (int u = 0; u < UPW; ++u) { w0[u] = wa[u][c * 64]; w1[u] = wa[u][(c + 8) * 64]; }
-                        while (true) {
-                            const int cn = c + 1;
-                            const bool more = cn < CE;
-                            float ne0 = 0.f, ne1 = 0.f, nw0[UPW], nw1[UPW];
-                            if (more) {
-                                ne0 = eb[4 * cn * Dp]; ne1 = eb[4 * cn * Dp + 1];
-#pragma clang loop unroll(full)
-                                for (int u = 0; u < UPW; ++u) { nw0[u] = wa[u][cn * 64]; nw1[u] = wa[u][(cn + 8) * 64]; }
-                            }
+                for (int c = cs; c < CE; c += DEPTH) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        if (c + d < CE) {
 #pragma clang loop unroll(full)
                             for (int u = 0; u < UPW; ++u) {
-                                acc[u] = mfma16(e0, w0[u], acc[u]);
-                                acc[u] = mfma16(e1, w1[u], acc[u]);
+                                accA[u] = mfma16(ev0[d], wv0[d][u], accA[u]);
+                                accA[u] = mfma16(ev1[d], wv1[d][u], accA[u]);
                             }
-                            if (!more) break;
-                            e0 = ne0; e1 = ne1; c = cn;
-#pragma clang loop unroll(full)
-                            for (int u = 0; u < UPW; ++u) { w0[u] = nw0[u]; w1[u] = nw1[u]; }
+                            CFFM_A_REQ(d, c + d + DEPTH)
                         }
                     }
-#pragma clang loop unroll(full)
-                    for (int u = 0; u < UPW; ++u) {
-                        const int ml = wave * UPW + u;
-                        if (!okU[u]) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) Tg[ml * TGP + (kk * 4 + j) * 16 + r] = acc[u][j];
-                    }
                 }
-                if (g == 0) __syncthreads();                   // dCt staged
-                // ---- C: dT planes of the group, wave's columns UPW*wave .. UPW*wave + UPW-1 ---------------------------------
+#undef CFFM_A_REQ
+#pragma clang loop unroll(full)
+                for (int u = 0; u < UPW; ++u) {
+                    const int ml = wave * UPW + u;
+                    if (!okU[u]) accA[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Tg[ml * TGP + (kk * 4 + j) * 16 + r] = accA[u][j];
+                }
+                // The filter fragments of phase E: the first half of the wave's units is requested here (phases C and B hide the
+                // latency), the second half after phase C (all of them here: 64 live registers across phase C, spills; before
+                // phase A: more spills).
+                float4 we[UPW][4];
+                unsigned emask[UPW];
+#define CFFM_E_REQ(U0, U1)                                                                                                    \
+    _Pragma("clang loop unroll(full)") for (int u = (U0); u < (U1); ++u) {                                                    \
+        const float4* wep = WE + __builtin_amdgcn_readfirstlane((mU[u] * QT + qt) * 256);   /* wave-uniform */                 \
+        unsigned mk = 0;                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                       \
+            /* tile t holds rows n = 16t .. 16t+15 of (dw*F + j): empty when none of them has j > i */                        \
+            const int lo_max = min(F - 1, t * 16 + 15), hi_max = min(2 * F - 1, t * 16 + 15) - F;                             \
+            const int any = okU[u] & (t < NTE ? 1 : 0) &                                                                      \
+                            (((t * 16 < F ? 1 : 0) & (lo_max > iU[u] ? 1 : 0)) | ((t * 16 + 15 >= F ? 1 : 0) & (hi_max > iU[u] ? 1 : 0))); \
+            mk |= (unsigned)any << t;                                                                                         \
+        }                                                                                                                     \
+        emask[u] = mk;                                                                                                        \
+        /* UNCONDITIONAL loads (an empty tile re-reads the unit's last tile: an L1 hit): behind conditional loads hipcc     \
+           waits with vmcnt(0) in phase E - in the last row group that is a wait for the NEXT dC tile */                        \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) we[u][t] = (wep + (((mk >> t) & 1u) ? t : 3) * 64)[ulane];               \
+    }
+                CFFM_E_REQ(0, (UPW + 1) / 2)
+                // ---- C: dT planes of the group, wave's columns UPW*wave .. UPW*wave + UPW-1; K = y in halves of 16: the 4 + 4*UPW
+                //         operands of a half are requested together, then its 4*UPW MFMAs run ---------------------------------------
                 {
                     f32x4 acc[UPW];
 #pragma clang loop unroll(full)
                     for (int xl = 0; xl < UPW; ++xl) acc[xl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    for (int s4 = 0; s4 < S / 4; ++s4) {
-                        const int y = 4 * s4 + kk;
-                        const float av = mC_ok ? Es[iC * Dp + 2 * y + dhC] : 0.f;
+                    const float* ep = Es + iC * Dp + 2 * kk + dhC;
+                    const float* dp = dCt + kk * DCP + UPW * wave * 16 + r;
+                    // (hipcc moves every LDS read back in front of its MFMA - one exposed LDS round trip per two MFMAs - unless a
+                    //  scheduling barrier separates the requests from the arithmetic)
+#pragma clang loop unroll(disable)
+                    for (int h = 0; h < YT; ++h) {
+                        float av0[4], bv0[4][UPW];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            av0[s] = ep[32 * h + 8 * s];
 #pragma clang loop unroll(full)
-                        for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av, dCt[y * DCP + (UPW * wave + xl) * 16 + r], acc[xl]);
+                            for (int xl = 0; xl < UPW; ++xl) bv0[s][xl] = dp[(16 * h + 4 * s) * DCP + xl * 16];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma clang loop unroll(full)
+                            for (int xl = 0; xl < UPW; ++xl) acc[xl] = mfma16(av0[s], bv0[s][xl], acc[xl]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma clang loop unroll(full)
                     for (int xl = 0; xl < UPW; ++xl)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wave + xl) * 16 + r] = acc[xl][j];
                 }
-                // the filter fragments of phase E are requested here: phase B hides their latency
-                float4 we[UPW][4];
-                unsigned emask[UPW];
-#pragma clang loop unroll(full)
-                for (int u = 0; u < UPW; ++u) {
-                    const float4* wep = WE + (((int64_t)mU[u] * QT + qt) * 4) * 64 + lane;
-                    unsigned mk = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        // tile t holds rows n = 16t .. 16t+15 of (dw*F + j): empty when none of them has j > i
-                        const int lo_max = min(F - 1, t * 16 + 15), hi_max = min(2 * F - 1, t * 16 + 15) - F;
-                        const bool any = okU[u] && t < NTE && ((t * 16 < F && lo_max > iU[u]) || (t * 16 + 15 >= F && hi_max > iU[u]));
-                        if (any) { mk |= 1u << t; we[u][t] = wep[t * 64]; }
-                    }
-                    emask[u] = mk;
-                }
+                CFFM_E_REQ((UPW + 1) / 2, UPW)
+#undef CFFM_E_REQ
                 __syncthreads();                               // Tg and dTg written
-                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, KPW per wave), cols m -------------------
+                // ---- B: dEi of the group: rows y, K = (x,q) of this tile (64 k-steps, KPW per wave), cols m; operands of four
+                //         k-steps requested together (k index kf = 4*(wave*KPW + ks) + kk = x*16 + q) -----------------------------
+#define CFFM_PHASE_B_LOAD(K4, BV, A0, A1)                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                           \
+        BV[s] = tp[4 * ((K4) + s)]; A0[s] = dp[4 * ((K4) + s)];                                                               \
+        if (YT > 1) A1[s] = dp[16 * DCP + 4 * ((K4) + s)];                                                                    \
+    }                                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+#define CFFM_PHASE_B_MMA(GG, BV, A0, A1)                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                           \
+        accB[GG][0] = mfma16(A0[s], BV[s], accB[GG][0]);                                                                      \
+        if (YT > 1) accB[GG][1] = mfma16(A1[s], BV[s], accB[GG][1]);                                                          \
+    }                                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
 #define CFFM_PHASE_B(GG)                                                                                                      \
-    for (int ks = 0; ks < KPW; ++ks) {                                                                                        \
-        const int kf = 4 * (wave * KPW + ks) + kk, x = kf >> 4, q = kf & 15;                                                  \
-        const float bv = Tg[r * TGP + x * 16 + q];                                                                            \
-        accB[GG][0] = mfma16(dCt[r * DCP + x * 16 + q], bv, accB[GG][0]);                                                     \
-        if (YT > 1) accB[GG][1] = mfma16(dCt[(16 + r) * DCP + x * 16 + q], bv, accB[GG][1]);                                  \
+    {   /* (two operand sets - chunk n+1 requested before chunk n is multiplied - spill 59 registers at NW = 4) */            \
+        const float* tp = Tg + r * TGP + 4 * wave * KPW + kk;                                                                 \
+        const float* dp = dCt + r * DCP + 4 * wave * KPW + kk;                                                                \
+        _Pragma("unroll") for (int k4 = 0; k4 < KPW; k4 += 4) {                                                               \
+            float bA[4], aA0[4], aA1[4];                                                                                      \
+            CFFM_PHASE_B_LOAD(k4, bA, aA0, aA1)                                                                               \
+            CFFM_PHASE_B_MMA(GG, bA, aA0, aA1)                                                                                \
+        }                                                                                                                     \
     }
                 switch (g) {
                     case 0: CFFM_PHASE_B(0) break;
@@ -3423,12 +3439,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
                     default: CFFM_PHASE_B(3) break;
                 }
 #undef CFFM_PHASE_B
+#undef CFFM_PHASE_B_LOAD
+#undef CFFM_PHASE_B_MMA
                 // ---- E: dEj rows (dw,j), K = q, cols x: this wave's units ------------------------------------------------------
 #define CFFM_PHASE_E(XT)                                                                                                      \
     _Pragma("clang loop unroll(full)") for (int u = 0; u < UPW; ++u) {                                                        \
         if (emask[u] == 0) continue;                                                                                          \
-        const int ml = wave * UPW + u;                                                                                        \
-        const float4 bv = *reinterpret_cast<const float4*>(dTg + (ml * 16 + r) * 16 + 4 * kk);   /* [k = q = 4kk+c][n = x = r] */ \
+        const float4 bv = bvE[u];                                                                                             \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                       \
             if (!((emask[u] >> t) & 1u)) continue;                                                                            \
             const float4 wv = we[u][t];                                                                                       \
@@ -3438,12 +3455,25 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
             accE[XT][t] = mfma16(wv.w, bv.w, accE[XT][t]);                                                                    \
         }                                                                                                                     \
     }
-                if (xt == 0) { CFFM_PHASE_E(0) } else { CFFM_PHASE_E(1) }
+                // the dT operands of the phase are read BEFORE the next tile is requested: hipcc puts a full vmcnt(0) in front of
+                // any LDS read that follows a global_load_lds (it cannot tell dTg from dCt)
+                float4 bvE[UPW];
+#pragma clang loop unroll(full)
+                for (int u = 0; u < UPW; ++u)
+                    bvE[u] = *reinterpret_cast<const float4*>(dTg + ((wave * UPW + u) * 16 + r) * 16 + 4 * kk);   // [k = q = 4kk+c][n = x = r]
+                if (g == G - 1) {                              // (phase E twice in the source: its waits for the fragments must
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __syncthreads();                           //  not see the tile request as possibly older than they are)
+                    const bool nq = qt + 1 < QT, nxt = xt + 1 < RT;   // clamped to the last tile: a harmless re-read at the very end
+                    fetch_tile(nq ? x0 : (nxt ? x0 + 16 : x0), nq ? q0 + 16 : (nxt ? 0 : q0));
+                    if (xt == 0) { CFFM_PHASE_E(0) } else { CFFM_PHASE_E(1) }
+                } else {
+                    if (xt == 0) { CFFM_PHASE_E(0) } else { CFFM_PHASE_E(1) }
+                }
 #undef CFFM_PHASE_E
             }
         }
     }
-#undef CFFM_TILE_FETCH2
     // ---- dEi: sum the wavefronts' K slices, group by group ------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -3504,8 +3534,8 @@ static int launch_conv0_fact_tile_dgrad2(const DgradArgs& a, float* wpack, hipSt
     float4* WE = reinterpret_cast<float4*>(wpack + (int64_t)2 * a.F * QT * 1024);
     hipLaunchKernelGGL(pack_w0_tile_kernel, dim3(2 * a.F * QT), dim3(256), 0, st, a.W, WA, WE, a.F, a.Pp);
     CFFM_CHECK_LAUNCH();
-    // Es [4*CE][D+1] | dCt [32][260] | Tg [16][258] | dTg [4096]
-    const size_t lds = (size_t)((4 * CE * (a.D + 1) + 3) / 4 * 4 + 32 * 260 + 16 * 258 + 4096) * 4 + 16;
+    // Es [4*CE + 1][D+1] | dCt [32][260] | Tg [16][258] | dTg [4096]
+    const size_t lds = (size_t)(((4 * CE + 1) * (a.D + 1) + 3) / 4 * 4 + 32 * 260 + 16 * 258 + 4096) * 4 + 16;
     int rc = set_lds(conv0_fact_tile_dgrad2_kernel<32, NW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((conv0_fact_tile_dgrad2_kernel<32, NW>), dim3(a.B), dim3(64 * NW), lds, st, a, (const float*)WA, (const float4*)WE);
@@ -3532,7 +3562,184 @@ static int launch_conv0_fact_tile_dgrad(const DgradArgs& a, hipStream_t st, floa
     return 0;
 }
 
-static int launch_conv0_fact_tile_fwd(const ConvArgs& a, hipStream_t st) {
+// Layer-0 forward of the wide shapes, ONE workgroup per example walking the (column tile, channel tile) pairs - the round-2
+// kernel above launches a workgroup per (example, tile): 508 K workgroups at F32 D64 B8192, each of which gathers the
+// example's 32 embedding rows again, and with every load, MFMA and store switched off it still ran 11.6 of its 29 ms.  Here
+// the rows are staged once per example, step 1 reads the filter as the pre-packed fragments WA of the input gradient
+// (pack_w0_tile_kernel: one load at (wave-uniform base)[lane] per fragment, zeros where j <= i), its E operands stay in
+// registers across the channel tiles of a column tile, and the units are dealt to the wavefronts in balanced pairs of
+// passes: wavefront (dh, w') takes fields i = 4w' .. 4w'+3 (k-steps w' .. 7) and i = 28-4w' .. 31-4w' (k-steps 7-w' .. 7):
+// 72 MFMAs each, where consecutive units per wavefront gave 128 / 96 / 64 / 32.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void conv0_fact_tile_fwd2_kernel(ConvArgs a, const float* __restrict__ WA) {
+    static_assert(NW == 8, "unit passes below are laid out for 8 wavefronts: (dh, w') = (wave >> 2, wave & 3)");
+    constexpr int NTH = 64 * NW, XQ = 16 / NW, TP = 16 * 16 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = a.F, D = a.D, S = D / 2, RT = S / 16, PpT = a.Pp, QT = PpT / 16;
+    const int CE = (F + 3) / 4, Fp = 4 * CE, FpZ = Fp + 1, SP = S + 1, K2p = 2 * Fp;
+    // The embedding rows are kept DE-INTERLEAVED, E2[(d, f)][z] = E_f[2z + d] (rows f = F .. Fp zero): both steps read this one
+    // matrix as an MFMA operand - step 1 as [(dw, j)][x], step 2 as [(dh, i)][y] - at lane-constant offset + scalar.
+    float* T = reinterpret_cast<float*>(smem);                 // [K2p][TP]  planes m = dh*Fp + i (planes of i >= F stay zero)
+    float* E2 = T + K2p * TP;                                   // [2][FpZ][SP]
+    float* PS = E2 + (2 * FpZ * SP + 3) / 4 * 4;                // [NW][S] pool partials of the wavefronts
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
+    const unsigned ulane = lane;
+    const int b = blockIdx.x;
+    {
+        const float invD = 1.f / (float)D;
+        for (int e = tid; e < F * D; e += NTH) {
+            const int f = (int)(((float)e + 0.5f) * invD), d = e - f * D;
+            const float v = a.idx == nullptr ? a.in[((int64_t)b * F + f) * D + d] : row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D)[d];
+            E2[((d & 1) * FpZ + f) * SP + (d >> 1)] = v;
+        }
+        for (int e = tid; e < 2 * (FpZ - F) * SP; e += NTH) {
+            const int d = e / ((FpZ - F) * SP), o = e - d * (FpZ - F) * SP;
+            E2[(d * FpZ + F) * SP + o] = 0.f;
+        }
+        for (int e = tid; e < 2 * (Fp - F) * TP; e += NTH) {   // the planes of the padding fields
+            const int d = e / ((Fp - F) * TP), o = e - d * (Fp - F) * TP;
+            T[(d * Fp + F) * TP + o] = 0.f;
+        }
+    }
+    const int dhW = wave >> 2, wq = wave & 3;
+    float* outb = a.out + (int64_t)b * S * S * PpT;
+    const float* e2l = E2 + kk * SP + r;                        // lane-constant part of both operand addresses
+    const float* tl = T + kk * TP + r;
+    lds_barrier();
+#pragma clang loop unroll(disable)
+    for (int xt = 0; xt < RT; ++xt) {
+        const int x0 = xt * 16;
+#pragma clang loop unroll(disable)
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q0 = qt * 16;
+            // ---- step 1: T planes of this wavefront's units, two passes of four consecutive fields -------------------------
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int i0 = pass == 0 ? 4 * wq : 28 - 4 * wq;
+                if (i0 >= F) continue;                          // wave-uniform
+                const int cs = (i0 + 1) >> 2;                   // first k-step with a field j > i0
+                f32x4 acc[4];
+                const float* wa[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int m = dhW * F + min(i0 + u, F - 1);
+                    wa[u] = WA + __builtin_amdgcn_readfirstlane((m * QT + qt) * 1024);
+                }
+                // k-steps cs .. CE-1 in a run-time loop, DEPTH of them in flight (k-step d + DEPTH is requested when k-step d is
+                // multiplied).  (All eight unrolled behind wave-uniform tests: every fragment was spilled right after its load.)
+                constexpr int DEPTH = 3;
+                float w0[DEPTH][4], w1[DEPTH][4], e0[DEPTH], e1[DEPTH];
+#define CFFM_F_REQ(SLOT, C)                                                                                                   \
+    if ((C) < CE) {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                       \
+            w0[SLOT][u] = (wa[u] + (C) * 64)[ulane]; w1[SLOT][u] = (wa[u] + ((C) + 8) * 64)[ulane];                           \
+        }                                                                                                                     \
+        e0[SLOT] = e2l[4 * (C) * SP + x0]; e1[SLOT] = e2l[(FpZ + 4 * (C)) * SP + x0];                                         \
+    }
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) { CFFM_F_REQ(d, cs + d) }
+                for (int c = cs; c < CE; c += DEPTH) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        if (c + d < CE) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc[u] = mfma16(e0[d], w0[d][u], acc[u]);
+                                acc[u] = mfma16(e1[d], w1[d][u], acc[u]);
+                            }
+                            CFFM_F_REQ(d, c + d + DEPTH)
+                        }
+                    }
+                }
+#undef CFFM_F_REQ
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u >= F) continue;
+                    float* tp = T + (dhW * Fp + i0 + u) * TP + r;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tp[(kk * 4 + j) * 16] = acc[u][j];
+                }
+            }
+            lds_barrier();                                      // T written (and the pool partials of the previous tile read)
+            // ---- step 2: C[y][x][q] = relu(b[q] + sum_k E_i[2y+dh] * T[k = (dh,i)][x][q]), this wavefront's XQ columns --------
+            const float bias = a.bias[q0 + r];
+            const int xg = wave * XQ;
+#pragma clang loop unroll(disable)
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 acc[XQ];
+#pragma unroll
+                for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(disable)
+                for (int dh = 0; dh < 2; ++dh) {                // K = (dh, i): per tap the CE k-steps of its Fp fields, requested together
+                    float av[8], bv[8][XQ];
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        const int sc = min(s2, CE - 1);
+                        av[s2] = e2l[(dh * FpZ + 4 * sc) * SP + rt * 16];
+#pragma unroll
+                        for (int q4 = 0; q4 < XQ; ++q4) bv[s2][q4] = tl[(dh * Fp + 4 * sc) * TP + (xg + q4) * 16];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        if (s2 >= CE) continue;
+#pragma unroll
+                        for (int q4 = 0; q4 < XQ; ++q4) acc[q4] = mfma16(av[s2], bv[s2][q4], acc[q4]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q4 = 0; q4 < XQ; ++q4)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int yy = rt * 16 + kk * 4 + j;
+                        const float c = fmaxf(acc[q4][j] + bias, 0.f);
+                        outb[((int64_t)yy * S + x0 + xg + q4) * PpT + q0 + r] = c;
+                        ps[j] += act_pos(c, a.act);
+                    }
+                if (a.pool != nullptr) {                        // pool partial of this (column tile, channel tile): over q in the DPP row
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = row_group_sum<true>(ps[j]);
+                        if (r == 0) PS[(wave * RT + rt) * 16 + kk * 4 + j] = v;      // [NW][S]
+                    }
+                }
+            }
+            lds_barrier();                                      // T consumed, pool partials written
+            if (a.pool != nullptr && tid < S) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += PS[w * S + tid];                  // wave order: x0 + w * XQ ascending
+                a.pool[((int64_t)b * S + tid) * a.pool_np + xt * QT + qt] = v;
+            }
+        }
+    }
+}
+
+static int launch_conv0_fact_tile_fwd2(const ConvArgs& a, float* wpack, hipStream_t st) {
+    constexpr int NW = 8;
+    const int QT = a.Pp / 16, CE = (a.F + 3) / 4, S = a.D / 2;
+    float* WA = wpack;
+    float4* WE = reinterpret_cast<float4*>(wpack + (int64_t)2 * a.F * QT * 1024);
+    hipLaunchKernelGGL(pack_w0_tile_kernel, dim3(2 * a.F * QT), dim3(256), 0, st, a.W, WA, WE, a.F, a.Pp);
+    CFFM_CHECK_LAUNCH();
+    // T [2*Fp][272] | E2 [2][Fp + 1][S + 1] | PS [NW][S]
+    const size_t lds = (size_t)(8 * CE * (16 * 16 + 16) + (2 * (4 * CE + 1) * (S + 1) + 3) / 4 * 4 + NW * S) * 4 + 16;
+    int rc = set_lds(conv0_fact_tile_fwd2_kernel<NW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv0_fact_tile_fwd2_kernel<NW>), dim3(a.B), dim3(64 * NW), lds, st, a, (const float*)WA);
+    CFFM_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_conv0_fact_tile_fwd(const ConvArgs& a, hipStream_t st, float* wpack = nullptr) {
+    {
+        const char* ver = getenv("CFFM_TILE_FWD");              // debug: 1 = the round-2 kernel (a workgroup per tile)
+        if (wpack != nullptr && a.F <= 32 && a.D / 2 <= 32 && !(ver && ver[0] == '1')) return launch_conv0_fact_tile_fwd2(a, wpack, st);
+    }
+
     constexpr int NW = 8;                // measured at F32 D64 B8192: 38.6 ms with 4 wavefronts, 29.2 with 8, 36.6 with 16 (one workgroup per CU)
     const int S = a.D / 2;
     const size_t lds = (size_t)(2 * a.F * (16 * 16 + 16) + a.F * (a.D + 1) + NW * S) * 4 + 16;
@@ -3738,7 +3945,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     // rank-1 input channels: factorised, channel-tiled (its step 1 indexes k over ALL fields: 2 * ceil4(F) <= 64 k values)
     if (l == 0 && conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS) {
         if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; }     // rows straight from the outer table (RowSrc)
-        return launch_conv0_fact_tile_fwd(a, st);
+        return launch_conv0_fact_tile_fwd(a, st, wl.w0pack_floats > 0 ? (float*)(w + wl.w0pack) : nullptr);
     }
     if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;                  // cffm_wide_regather_ok() guards the callers
     pick_nt(g.Pp / 16, &nblk, &NT);
