@@ -2808,6 +2808,30 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
     for (int u4 = 0; u4 < UPW; ++u4)
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) accD[u4][t4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Phase D multiplies rows n = dw*F + j over ALL fields (rows with j <= i are computed and dropped): the operand address of row
+    // tile t is then a lane constant (4 registers) + a scalar, shared by the wavefront's units - with the rows compressed to j > i
+    // every MFMA carried ten integer instructions of (unit, tile) -> (dw, j) arithmetic and two selects.  A tile none of whose rows
+    // has j > i is skipped (wave-uniform mask per unit).
+    int offD[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        const int n = t4 * 16 + r, dwn = n >= F ? 1 : 0, jn = n - dwn * F;
+        offD[t4] = (n < 2 * F ? jn * Dp + dwn : 0) + 2 * kk;
+    }
+    unsigned mkU[UPW];
+#pragma unroll
+    for (int u4 = 0; u4 < UPW; ++u4) {
+        const int m = g * 16 + wl * UPW + u4, dh = m >= F ? 1 : 0, i = m - dh * F;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int lo_max = min(F - 1, t4 * 16 + 15), hi_max = min(2 * F - 1, t4 * 16 + 15) - F;
+            const int any = (g_on && m < 2 * F ? 1 : 0) & (t4 * 16 < 2 * F ? 1 : 0) &
+                            (((t4 * 16 < F ? 1 : 0) & (lo_max > i ? 1 : 0)) | ((t4 * 16 + 15 >= F ? 1 : 0) & (hi_max > i ? 1 : 0)));
+            mk |= (unsigned)any << t4;
+        }
+        mkU[u4] = __builtin_amdgcn_readfirstlane(mk);
+    }
     float bsum = 0.f;                                          // bias partial of channel q0 + (gtid & 15), rows gtid >> 4 (group 0 only)
     // fetch of tile (b, xt) into buffer `buf`: dC pieces e4 = tid, tid + 1024 (S * 64 of them), embedding rows f = wave, wave + 16
     auto fetch_tile = [&](int b, int xt, int buf) {
@@ -2865,32 +2889,28 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
                     for (int j = 0; j < 4; ++j) dTg[((kk * 4 + j) * 16 + UPW * wl + xl) * 16 + r] = acc[xl][j];
             }
             __syncthreads();
-            // ---- phase D: the wave's four units -----------------------------------------------------------------------
+            // ---- phase D: the wave's units: rows (dw,j) of ALL fields, K = x, cols q -----------------------------------
             if (g_on) {
-                // The per-(unit, tile) row offsets below are loop invariants; hoisted out of the tile loop they do not fit the
-                // 128-register budget next to the 64 accumulation registers and come back as scratch reloads (two L2 round
-                // trips in front of every block of 16 MFMAs: 28.2 ms).  An opaque zero keeps their six VALU instructions here.
-                int opq;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+                float bvv[UPW][4];
 #pragma unroll
-                for (int u4 = 0; u4 < UPW; ++u4) {
-                    const int ml = wl * UPW + u4, m = g * 16 + ml;
-                    if (m >= 2 * F) continue;
-                    const int dh = m >= F ? 1 : 0, i = m - dh * F;
-                    (void)dh;
-                    const int nj = F - 1 - i, K2 = 2 * nj;
+                for (int u4 = 0; u4 < UPW; ++u4)
 #pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) {
-                        if (t4 * 16 >= K2) continue;
-                        const int m2 = t4 * 16 + r + opq;
-                        const bool ok = m2 < K2;
-                        const int dw = (ok && m2 >= nj) ? 1 : 0, jj = ok ? m2 - dw * nj : 0;
+                    for (int s4 = 0; s4 < 4; ++s4) bvv[u4][s4] = dTg[((wl * UPW + u4) * 16 + 4 * s4 + kk) * 16 + r];
+                const float* ex = Es + 2 * x0;
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const int x = 4 * s4 + kk;
-                            const float av = ok ? Es[(i + 1 + jj) * Dp + 2 * (x0 + x) + dw] : 0.f;
-                            accD[u4][t4] = mfma16(av, dTg[(ml * 16 + x) * 16 + r], accD[u4][t4]);
-                        }
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    unsigned anyu = 0;
+#pragma unroll
+                    for (int u4 = 0; u4 < UPW; ++u4) anyu |= (mkU[u4] >> t4) & 1u;
+                    if (!anyu) continue;
+                    float av[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) av[s4] = ex[offD[t4] + 8 * s4];
+#pragma unroll
+                    for (int u4 = 0; u4 < UPW; ++u4) {
+                        if (!((mkU[u4] >> t4) & 1u)) continue;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) accD[u4][t4] = mfma16(av[s4], bvv[u4][s4], accD[u4][t4]);
                     }
                 }
             }
@@ -2902,18 +2922,14 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
         for (int u4 = 0; u4 < UPW; ++u4) {
             const int m = g * 16 + wl * UPW + u4;
             if (m >= 2 * F) continue;
-            const int dh = m >= F ? 1 : 0, i = m - dh * F;
-            const int nj = F - 1 - i, K2 = 2 * nj, base = i * (2 * F - i - 1) / 2;
+            const int dh = m >= F ? 1 : 0, i = m - dh * F, base = i * (2 * F - i - 1) / 2;
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
-                if (t4 * 16 >= K2) continue;
+                if (!((mkU[u4] >> t4) & 1u)) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int m2 = t4 * 16 + kk * 4 + j;
-                    if (m2 < K2) {
-                        const int dw = m2 >= nj ? 1 : 0, jj = m2 - dw * nj;
-                        sw[((int64_t)(dh * 2 + dw) * PpT + base + jj) * PpT + q0 + r] = accD[u4][t4][j];
-                    }
+                    const int n = t4 * 16 + kk * 4 + j, dwn = n >= F ? 1 : 0, jn = n - dwn * F;
+                    if (n < 2 * F && jn > i) sw[((int64_t)(dh * 2 + dwn) * PpT + base + jn - i - 1) * PpT + q0 + r] = accD[u4][t4][j];
                 }
             }
         }
@@ -2938,9 +2954,12 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
 static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream_t st) {
     const int S = a.D / 2, G = (2 * a.F + 15) / 16;
     if (S > 32) return CFFM_ERR_UNSUPPORTED;
-    const char* ver = getenv("CFFM_TILE_WGRAD");                // debug: 1 = round-2 kernel, 4 = four groups per workgroup
+    const char* ver = getenv("CFFM_TILE_WGRAD");                // debug: 1 = round-2 kernel, 2 = two groups per workgroup
     if (G <= 4 && !(ver && ver[0] == '1')) {
-        if (ver && ver[0] == '4') {
+        if (!(ver && ver[0] == '2')) {
+            // all four groups in one workgroup of 16 wavefronts: the dC tile is staged ONCE per (example, column tile); 4 units per
+            // wavefront, 64 accumulation registers - 122 registers and nothing spilled since phase D stopped computing an operand
+            // address per MFMA (before: 31-49 spilled, slower than two groups)
             const size_t lds = (size_t)(2 * ((a.F * (a.D + 1) + 3) / 4 * 4) + 2 * 32 * 256 + 4 * 16 * 256) * 4 + 16;
             int rc = set_lds(conv0_fact_tile_wgrad_all_kernel<32, 4>, lds);
             if (rc) return rc;
@@ -2949,7 +2968,7 @@ static int launch_conv0_fact_tile_wgrad(const WgradArgs& a, int nslab, hipStream
             CFFM_CHECK_LAUNCH();
             return 0;
         }
-        // two groups per workgroup of 16 wavefronts: the tile is staged twice instead of four times, nothing spills
+        // two groups per workgroup: the tile is staged twice
         const size_t lds = (size_t)(2 * ((a.F * (a.D + 1) + 3) / 4 * 4) + 2 * 32 * 256 + 2 * 16 * 256) * 4 + 16;
         int rc = set_lds(conv0_fact_tile_wgrad_all_kernel<32, 2>, lds);
         if (rc) return rc;
