@@ -15,7 +15,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libcffm_hip.so')
+LIB_PATH = os.environ.get('CFFM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcffm_hip.so')   # CFFM_HIP_LIB: another build of the library (A/B timing of kernel variants)
 
 ABI_VERSION = 7
 MAX_LAYERS = 8
