@@ -311,6 +311,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # CFFM_BENCH_REHEARSAL=1 (debug): every rank on cuda:0 over gloo - how the N > 1 flow of this file (sharding of the batches, the
+    # barriers, MAX over the ranks, the replica check, the JSON line) is rehearsed on a ONE-GPU box, where RCCL cannot be given
+    # two devices.  Its numbers mean nothing (N processes share one GPU, the collectives go through the host).
+    rehearsal = bool(os.environ.get('CFFM_BENCH_REHEARSAL'))
+    if rehearsal:
+        local_rank = 0
     use_pg = world > 1 or args.tables == 'sharded' or args.force_dp
     if use_pg:
         import torch.distributed as dist
@@ -318,7 +324,10 @@ def main():
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)'
                          % (args.gpus, world))

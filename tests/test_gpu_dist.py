@@ -1,0 +1,132 @@
+"""N > 1 path ON THE GPU: two ranks on cuda:0 over gloo (a one-GPU box cannot give RCCL two devices, and gloo moves device
+tensors by itself), so that the multi-rank code of cffm_amd.dist runs against the real HIP kernels before an 8-GPU node sees
+it: DataParallelStep (dense-image route and all-gather route) and ShardedStep at world size 2 must leave every rank with
+what ONE HipEngine gets from the whole batch.  The collectives differ from the product's only in the backend name.
+
+What is compared: the state after each of two consecutive train steps.  In the FIRST step every example is computed by the same
+kernels from the same parameters in both runs, so the forward is bit-identical and the gradients differ by summation order
+only (per-rank loss sums, slab grouping, duplicates of an id across ranks: a few 1e-7 relative): 1e-4 relative / 2e-6 absolute,
+four orders of magnitude below what a wrong 1/B, a lost rank or a mis-routed row would produce.  The SECOND step starts from
+states that already differ in the last bits, and Adagrad from 1e-8 accumulators amplifies that (free-running
+trajectories are not comparable element by element): 90 % of a tensor's elements within 2e-2 relative / 2e-4 absolute, which
+shows that the step runs on updated accumulators and re-used plans and still excludes a wrong scale."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cffm_amd.spec import CFFMConfig, init_params  # noqa: E402
+from tests import test_dist_cpu as H  # noqa: E402   (the spawn / gloo harness)
+
+pytestmark = pytest.mark.gpu
+TABLES = ('inner_embeddings', 'outer_embeddings', 'feature_bias')
+
+
+def _case():
+    cfg = CFFMConfig(M=800, F=10, K=32, D=32, activation='selu')            # the frappe command's shape, small vocabulary
+    rng = np.random.default_rng(11)
+    X = rng.integers(0, cfg.M, size=(2, 128, cfg.F)).astype(np.int32)
+    X[:, 70] = X[:, 3]                                                       # the same ids on both ranks: cross-rank duplicates
+    y = rng.choice([-1.0, 1.0], size=(2, 128)).astype(np.float32)
+    return cfg, X, y
+
+
+def _dp_worker(rank, world, mode):
+    from cffm_amd.dist import DataParallelStep
+    from cffm_amd.engine import HipEngine
+    cfg, X, y = _case()
+    eng = HipEngine(cfg, params=init_params(cfg, seed=7 + rank), device='cuda:0')   # different draws: rank 0's must win
+    dp = DataParallelStep(eng, mode=mode)
+    per = X.shape[1] // world
+    sl = slice(rank * per, rank * per + per)
+    out = []
+    for s in range(X.shape[0]):
+        loss = dp.train_step(torch.from_numpy(X[s, sl].copy()).cuda(), torch.from_numpy(y[s, sl].copy()).cuda())
+        torch.cuda.synchronize()
+        out.append((float(loss.cpu().reshape(-1)[0]), eng.export_params(), eng.export_accumulators()))
+    return out
+
+
+def _sharded_worker(rank, world, ahead):
+    from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
+    from cffm_amd.engine import HipEngine
+    cfg, X, y = _case()
+    lcfg = copy.copy(cfg)
+    lcfg.M = local_rows_count(cfg.M, rank, world)
+    eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=7), rank, world), device='cuda:0')
+    sh = ShardedStep(eng)
+    per = X.shape[1] // world
+    sl = slice(rank * per, rank * per + per)
+    ids = [torch.from_numpy(X[s, sl].copy()).cuda() for s in range(X.shape[0])]
+    ys = [torch.from_numpy(y[s, sl].copy()).cuda() for s in range(X.shape[0])]
+    out = []
+    for s in range(len(ids)):
+        nxt = ids[s + 1] if ahead and s + 1 < len(ids) else None
+        loss = sh.train_step(ids[s], ys[s], next_ids=nxt)
+        torch.cuda.synchronize()
+        out.append((float(loss.cpu().reshape(-1)[0]), eng.export_params(), None))
+    return out, (sh.plans_built, sh.plans_reused)
+
+
+def _single():
+    from cffm_amd.engine import HipEngine
+    cfg, X, y = _case()
+    eng = HipEngine(cfg, params=init_params(cfg, seed=7), device='cuda:0')
+    out = []
+    for s in range(X.shape[0]):
+        loss = eng.train_step(torch.from_numpy(X[s]).cuda(), torch.from_numpy(y[s]).cuda())
+        torch.cuda.synchronize()
+        out.append((float(loss.cpu().reshape(-1)[0]), eng.export_params(), eng.export_accumulators()))
+    return out
+
+
+def _same(a, b, what, step):
+    """Step 0: 99.8 % of the elements within 1e-4 relative / 2e-6 absolute and EVERY element within 5e-4 * (1 + |ref|).  (The handful
+    beyond the first bound are parameters whose gradient nearly cancels: the first Adagrad step from a 1e-8 accumulator,
+    u(g) = lr*g/sqrt(1e-8 + g^2), has slope lr*1e4 at g = 0, so one ulp of a 0.5-sized partial sum taken in another order
+    moves the parameter by 3e-5.  A wrong scale moves EVERY updated element by a fraction of lr = 0.05.)
+    Step 1 (a sanity check of a free-running second step, see the header): 90 % within 2e-2 / 2e-4, every element within
+    0.2 * (1 + |ref|)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    rtol, atol, frac, hard = [(1e-4, 2e-6, 0.998, 5e-4), (2e-2, 2e-4, 0.90, 0.2)][step]
+    err = np.abs(a - b)
+    ok = err <= atol + rtol * np.abs(b)
+    worst = float((err / (1.0 + np.abs(b))).max())            # the hard bound is relative for large values (accumulators)
+    assert ok.mean() >= frac and worst <= hard, 'step %d: %s: %.4f %% within tolerance, worst error/(1+|ref|) %.3g' % (
+        step, what, 100 * ok.mean(), worst)
+
+
+@pytest.mark.parametrize('mode', ['dense', 'gather'])
+def test_data_parallel_world2_on_the_gpu_equals_one_engine(mode):
+    res = H._run(_dp_worker, 2, mode)
+    ref = _single()
+    for step, (L, p, acc) in enumerate(ref):
+        for rank in (0, 1):
+            loss, got, gacc = res[rank][step]
+            _same(loss, L, 'rank %d loss' % rank, step)
+            for k in acc:        # the TRAINED variables (outer_W / outer_b and the dead last conv layer stay on the host, untouched
+                _same(got[k], p[k], 'rank %d %s' % (rank, k), step)                      # by the step and by the broadcast)
+                _same(gacc[k], acc[k], 'rank %d accumulator of %s' % (rank, k), step)
+        for k in acc:                                                        # the replicas stay bit-identical
+            np.testing.assert_array_equal(np.asarray(res[0][step][1][k]), np.asarray(res[1][step][1][k]), err_msg=k)
+
+
+@pytest.mark.parametrize('ahead', [False, True])
+def test_row_sharded_world2_on_the_gpu_equals_one_engine(ahead):
+    res = H._run(_sharded_worker, 2, ahead)
+    ref = _single()
+    for rank in (0, 1):
+        steps, (built, reused) = res[rank]
+        assert reused == (1 if ahead else 0) and built == 2
+        for step, (L, p, acc) in enumerate(ref):
+            loss, got, _ = steps[step]
+            _same(loss, L, 'rank %d loss' % rank, step)
+            for k in acc:
+                want = np.asarray(p[k])[rank::2] if k in TABLES else p[k]
+                _same(got[k], want, 'rank %d %s' % (rank, k), step)
