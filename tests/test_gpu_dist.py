@@ -130,3 +130,41 @@ def test_row_sharded_world2_on_the_gpu_equals_one_engine(ahead):
             for k in acc:
                 want = np.asarray(p[k])[rank::2] if k in TABLES else p[k]
                 _same(got[k], want, 'rank %d %s' % (rank, k), step)
+
+
+def _cffm_class_worker(rank, world, tmp):
+    """The drop-in class with its real HipEngine under a process group the caller initialised (tests/test_dist_cpu.py runs the
+    same flow with the oracle standing in for the engine)."""
+    from cffm_amd import CFFM as M
+    from cffm_amd import synth
+
+    class Split(dict):
+        pass
+
+    rng = np.random.default_rng(11)
+    Mf, F = 40, 4
+
+    def split(n):
+        return Split(X=synth.sample_ids(rng, Mf, F, n).tolist(), Y=synth.sample_labels(rng, n).tolist())
+
+    class Data(object):
+        pass
+    data = Data()
+    data.Train_data, data.Validation_data, data.Test_data = split(37), split(11), split(9)
+    m = M.CFFM(Mf, 0, os.path.join(tmp, 'g%d_w%d' % (rank, world)), 8, 8, 'square_loss', 2, 8, 0.05, 0, [1.0, 1.0],
+               'AdagradOptimizer', 0, 0, 0, F, 1, 0, 1.0, 1, 1.0, 1, 1.0, 'relu')
+    np.random.seed(77)                                       # the reference's batch starts are unseeded: pin them for the test
+    m.train(data)
+    assert m.world == world and (m._dp is not None) == (world > 1)
+    return (m.train_rmse, m.valid_rmse, m.test_rmse, m.train_r2), m.engine.export_params()
+
+
+def test_cffm_class_trains_data_parallel_on_the_gpu(tmp_path):
+    one = H._run(_cffm_class_worker, 1, str(tmp_path))[0]
+    two = H._run(_cffm_class_worker, 2, str(tmp_path))
+    for a, b in zip(two[0][0], two[1][0]):                   # per-epoch metrics: the SAME numbers on both ranks ...
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    for k in two[0][1]:                                      # ... from bit-identical replicas
+        np.testing.assert_array_equal(np.asarray(two[0][1][k]), np.asarray(two[1][1][k]), err_msg=k)
+    for a, b in zip(one[0], two[0][0]):                      # and the single-process run's, up to fp32 summation order over two
+        np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=2e-2, atol=2e-3)   # free-running epochs (header)
