@@ -450,6 +450,11 @@ def main():
             res['roofline']['measured_peaks'] = measured_peaks(device)
             if not args.no_cpu_baseline and not big:
                 res['cpu_baseline'] = cpu_baseline(cfg, Xh, yh)
+        elif world > 1 and not args.quick and args.tables == 'replicated':
+            # N > 1: the roofline object of the dominant gather kernel again, measured on rank 0's GPU once the timed blocks are
+            # over (the other ranks wait at the final barrier; cpu_baseline is an N = 1 figure by contract)
+            del X, y
+            res['roofline'] = gather_roofline(device)
         print(json.dumps(res), flush=True)
     if use_pg:
         dist.barrier()
