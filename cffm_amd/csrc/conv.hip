@@ -191,6 +191,7 @@ struct ConvArgs {
     int idxM = 0;
     float* pool = nullptr;          // wide shapes: partial sum pools of act(out), [B][So][pool_np] (pool_partials(), common.hpp)
     int pool_np = 0;
+    uint16_t* relu = nullptr;       // tiled layer-0 forward: bit mask of out > 0, [B*So*So][Pp/16] 16-bit words (ws.relu0)
 };
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
@@ -334,6 +335,7 @@ struct DgradArgs {
     int nblk;            // dgrad_kernel, L0 = false: column blocks of a row tile (1-D grid, see xcd_tile)
     const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = Cprev is the outer TABLE [M][D], row (b, f) = idx[b*F+f] (RowSrc)
     int idxM = 0;
+    const uint16_t* relu = nullptr; // dgrad_kernel, L0 = false: bit mask of C_{l-1} > 0 ([rows of C_{l-1}][Pp/16] words) read INSTEAD of C_{l-1}
 };
 
 // 3 wavefronts per SIMD for the 128 x 128 instance (166 VGPRs instead of 200, nothing spilled): 16.36 -> 14.80 ms per launch at
@@ -441,9 +443,15 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
                             if (nt >= nvalid) continue;
                             const int64_t pos = rowbase + noff[nt];
                             const float g = acc[rm][nt][j] + (ndh[nt] ? t1v : t0);
-                            const float c = a.Cprev[pos];
-                            float d = c > 0.f ? gsc : 0.f;
-                            if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
+                            float d;
+                            if (a.relu != nullptr) {           // one 16-bit word per (pixel, 16 channels): the 16 lanes of a row share it
+                                const uint32_t wmask = a.relu[(pos - r) >> 4];   // (Pp is a multiple of 16: lane r is channel (word, r))
+                                d = ((wmask >> r) & 1u) ? gsc : 0.f;
+                            } else {
+                                const float c = a.Cprev[pos];
+                                d = c > 0.f ? gsc : 0.f;
+                                if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
+                            }
                             a.dprev[pos] = g * d;
                         }
                     }
@@ -3709,6 +3717,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv0_fact_tile_fwd2_kernel(ConvAr
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float ps[4] = {0.f, 0.f, 0.f, 0.f};
+                unsigned long long mine = 0;                    // relu mask: lane (kk, r = 4*q4 + j) keeps the ballot of element (q4, j)
 #pragma unroll
                 for (int q4 = 0; q4 < XQ; ++q4)
 #pragma unroll
@@ -3717,7 +3726,13 @@ __global__ __launch_bounds__(64 * NW, 4) void conv0_fact_tile_fwd2_kernel(ConvAr
                         const float c = fmaxf(acc[q4][j] + bias, 0.f);
                         outb[((int64_t)yy * S + x0 + xg + q4) * PpT + q0 + r] = c;
                         ps[j] += act_pos(c, a.act);
+                        const unsigned long long bal = __ballot(c > 0.f);    // bits 16kk .. 16kk+15: the 16 channels of pixel (yy, x)
+                        if (r == 4 * q4 + j) mine = bal;
                     }
+                if (a.relu != nullptr && r < 4 * XQ) {          // ONE 2-byte store per lane (4*XQ*4 lanes) instead of one per ballot
+                    const int q4 = r >> 2, yy = rt * 16 + kk * 4 + (r & 3);
+                    a.relu[(((int64_t)b * S + yy) * S + x0 + xg + q4) * QT + qt] = (uint16_t)(mine >> (16 * kk));
+                }
                 if (a.pool != nullptr) {                        // pool partial of this (column tile, channel tile): over q in the DPP row
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -3936,6 +3951,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     a.Mtot = layer_rows(g, B, l, &a.lgSo);
     a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
     if (wl.pool_np[l] > 0) { a.pool = (float*)(w + wl.pool[l]); a.pool_np = wl.pool_np[l]; }   // wide shapes: the epilogue leaves the pool partials
+    if (l == 0 && wl.relu0 > 0) a.relu = (uint16_t*)(w + wl.relu0);   // ... and the relu mask of C_0 for the input gradient of layer 1
     int nblk, NT;
     int rc = 0;
     if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop
@@ -4167,6 +4183,10 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         a.Cprev = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dt1 = (const float*)(w + wl.dt1);
         a.dprev = (float*)(w + (l == 0 ? wl.dEo : wl.dC[l - 1]));
+        {   // layer 1 of the wide shapes reads the relu mask the tiled layer-0 forward left (1/32 of the bytes of C_0)
+            const char* oldfwd = getenv("CFFM_TILE_FWD");
+            if (l == 1 && wl.relu0 > 0 && !(oldfwd && oldfwd[0] == '1') && !getenv("CFFM_DGRAD_NO_MASK")) a.relu = (const uint16_t*)(w + wl.relu0);
+        }
         a.Mtot = layer_rows(g, B, l, &a.lgSo);
         a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
         a.t1w = 2 * g.D - 2; a.t1off = t1_offset(g, l);

@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CFFM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcffm_hip.so')   # CFFM_HIP_LIB: another build of the library (A/B timing of kernel variants)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
@@ -50,7 +50,7 @@ class WsLayout(C.Structure):
                 ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
                 ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64), ('Gfb', C.c_int64),
                 ('pool', C.c_int64 * MAX_LAYERS), ('pool_np', C.c_int32 * MAX_LAYERS),
-                ('w0pack', C.c_int64), ('w0pack_floats', C.c_int64)]
+                ('w0pack', C.c_int64), ('w0pack_floats', C.c_int64), ('relu0', C.c_int64)]
 
 
 class Tables(C.Structure):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 7
+#define CFFM_ABI_VERSION 8
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -108,6 +108,9 @@ typedef struct cffm_ws_layout {
                                                fragments for the input-gradient kernel (rebuilt from theta by every backward pass;
                                                0 = not used)                                                                        */
     int64_t w0pack_floats;
+    int64_t relu0;                          /* wide shapes with the tiled layer 0: one bit per element of C[0], set where C[0] > 0
+                                               (16-bit words: [B*S_0*S_0][Pp/16]), written by the layer-0 forward and read by the
+                                               input gradient of layer 1 instead of C[0] itself (0 = not used)                     */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
