@@ -2816,14 +2816,15 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
     for (int u4 = 0; u4 < UPW; ++u4)
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) accD[u4][t4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Phase D multiplies rows n = dw*F + j over ALL fields (rows with j <= i are computed and dropped): the operand address of row
+    // Phase D multiplies rows n = 2j + dw over ALL fields (rows with j <= i are computed and dropped; interleaved, the wanted rows
+    // are the last 2(F-1-i): 2.4 row tiles per unit on average at F = 32 where n = dw*F + j needed 3): the operand address of row
     // tile t is then a lane constant (4 registers) + a scalar, shared by the wavefront's units - with the rows compressed to j > i
     // every MFMA carried ten integer instructions of (unit, tile) -> (dw, j) arithmetic and two selects.  A tile none of whose rows
     // has j > i is skipped (wave-uniform mask per unit).
     int offD[4];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-        const int n = t4 * 16 + r, dwn = n >= F ? 1 : 0, jn = n - dwn * F;
+        const int n = t4 * 16 + r, dwn = n & 1, jn = n >> 1;
         offD[t4] = (n < 2 * F ? jn * Dp + dwn : 0) + 2 * kk;
     }
     unsigned mkU[UPW];
@@ -2833,9 +2834,7 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
         unsigned mk = 0;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-            const int lo_max = min(F - 1, t4 * 16 + 15), hi_max = min(2 * F - 1, t4 * 16 + 15) - F;
-            const int any = (g_on && m < 2 * F ? 1 : 0) & (t4 * 16 < 2 * F ? 1 : 0) &
-                            (((t4 * 16 < F ? 1 : 0) & (lo_max > i ? 1 : 0)) | ((t4 * 16 + 15 >= F ? 1 : 0) & (hi_max > i ? 1 : 0)));
+            const int any = (g_on && m < 2 * F ? 1 : 0) & (t4 * 16 < 2 * F ? 1 : 0) & (min(F - 1, 8 * t4 + 7) > i ? 1 : 0);
             mk |= (unsigned)any << t4;
         }
         mkU[u4] = __builtin_amdgcn_readfirstlane(mk);
@@ -2936,7 +2935,7 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
                 if (!((mkU[u4] >> t4) & 1u)) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = t4 * 16 + kk * 4 + j, dwn = n >= F ? 1 : 0, jn = n - dwn * F;
+                    const int n = t4 * 16 + kk * 4 + j, dwn = n & 1, jn = n >> 1;
                     if (n < 2 * F && jn > i) sw[((int64_t)(dh * 2 + dwn) * PpT + base + jn - i - 1) * PpT + q0 + r] = accD[u4][t4][j];
                 }
             }
@@ -3237,7 +3236,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
 // tiles (an instruction stream larger than the instruction cache); MFMA pipe busy 30 %.  Here the layer-0 filter is laid out
 // ONCE per backward pass (pack_w0_tile_kernel, 16 MB written, a few us) exactly as the two phases consume it:
 //   WA[m = (dh,i)][qt][ks = dw*8 + c][lane = (kk,r)]      = W[dh,dw,(i,j),q0+r],  j = 4c + kk  (0 where j <= i or j >= F)
-//   WE[m = (dh,i)][qt][t][lane = (kk,r)] (16 bytes)       = W[dh,dw,(i,j),q0+4kk .. +3],  row n = 16t + r = dw*F + j  (0 likewise)
+//   WE[m = (dh,i)][qt][t][lane = (kk,r)] (16 bytes)       = W[dh,dw,(i,j),q0+4kk .. +3],  row n = 16t + r = 2j + dw   (0 likewise)
 // so a fragment is ONE load at (wave-uniform base) + lane with no select, k of phase A runs over ALL fields (the E operand of
 // a k-step no longer depends on the unit: one LDS read pair feeds the wave's UPW units) and the k-steps whose fields all lie
 // at or below i are skipped (8.5 MFMAs per unit on average instead of 12).
@@ -3253,8 +3252,8 @@ __global__ __launch_bounds__(256) void pack_w0_tile_kernel(const float* __restri
         wa[e] = ok ? W[((int64_t)(dh * 2 + dw) * Pp + base + (j - i - 1)) * Pp + q0 + r] : 0.f;
     }
     {
-        const int t = tid >> 6, n = t * 16 + r, dw = n >= F ? 1 : 0, j = n - dw * F;
-        const bool ok = n < 2 * F && j > i;
+        const int t = tid >> 6, n = t * 16 + r, dw = n & 1, j = n >> 1;     // rows interleaved, n = 2j + dw: the rows with j > i are the
+        const bool ok = n < 2 * F && j > i;                                  // LAST 2(F-1-i) of them - whole leading tiles are empty
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) v = *reinterpret_cast<const float4*>(W + ((int64_t)(dh * 2 + dw) * Pp + base + (j - i - 1)) * Pp + q0 + 4 * kk);
         WE[(int64_t)blockIdx.x * 256 + tid] = v;
@@ -3389,10 +3388,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
         const float4* wep = WE + __builtin_amdgcn_readfirstlane((mU[u] * QT + qt) * 256);   /* wave-uniform */                 \
         unsigned mk = 0;                                                                                                      \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                       \
-            /* tile t holds rows n = 16t .. 16t+15 of (dw*F + j): empty when none of them has j > i */                        \
-            const int lo_max = min(F - 1, t * 16 + 15), hi_max = min(2 * F - 1, t * 16 + 15) - F;                             \
-            const int any = okU[u] & (t < NTE ? 1 : 0) &                                                                      \
-                            (((t * 16 < F ? 1 : 0) & (lo_max > iU[u] ? 1 : 0)) | ((t * 16 + 15 >= F ? 1 : 0) & (hi_max > iU[u] ? 1 : 0))); \
+            /* tile t holds rows n = 2j + dw = 16t .. 16t+15, i.e. fields 8t .. 8t+7: empty when none of them is > i */       \
+            const int any = okU[u] & (t < NTE ? 1 : 0) & (min(F - 1, 8 * t + 7) > iU[u] ? 1 : 0);                             \
             mk |= (unsigned)any << t;                                                                                         \
         }                                                                                                                     \
         emask[u] = mk;                                                                                                        \
@@ -3532,7 +3529,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += part[((w * 4 + t) * 64 + ln) * 4 + j];
-            const int n = t * 16 + (ln >> 4) * 4 + j, x = xt * 16 + (ln & 15);           // D layout: row (dw,j), col x
+            const int n = t * 16 + (ln >> 4) * 4 + j, x = xt * 16 + (ln & 15);           // D layout: row n = 2j + dw, col x
             dEj[n * SMAX + x] = v;
         }
     }
@@ -3549,7 +3546,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
         float R = 0.f, Q = 0.f;
         for (int j = f + 1; j < F; ++j) R += rs[j];
         for (int i = 0; i < f; ++i) Q += rs[F + i];
-        a.dprev[(int64_t)b * F * D + e] = (dEi[(lo * F + f) * SMAX + hh] + dEj[(lo * F + f) * SMAX + hh])
+        a.dprev[(int64_t)b * F * D + e] = (dEi[(lo * F + f) * SMAX + hh] + dEj[(2 * f + lo) * SMAX + hh])
                                           + a.dt1[(int64_t)b * a.t1w + h] * R + Q;
     }
 }
