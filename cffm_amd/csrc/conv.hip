@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
                                 d = c > 0.f ? gsc : 0.f;
                                 if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
                             }
-                            a.dprev[pos] = g * d;
+                            __builtin_nontemporal_store(g * d, &a.dprev[pos]);
                         }
                     }
                 }
@@ -3721,7 +3721,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv0_fact_tile_fwd2_kernel(ConvAr
                     for (int j = 0; j < 4; ++j) {
                         const int yy = rt * 16 + kk * 4 + j;
                         const float c = fmaxf(acc[q4][j] + bias, 0.f);
-                        outb[((int64_t)yy * S + x0 + xg + q4) * PpT + q0 + r] = c;
+                        __builtin_nontemporal_store(c, &outb[((int64_t)yy * S + x0 + xg + q4) * PpT + q0 + r]);
                         ps[j] += act_pos(c, a.act);
                         const unsigned long long bal = __ballot(c > 0.f);    // bits 16kk .. 16kk+15: the 16 channels of pixel (yy, x)
                         if (r == 4 * q4 + j) mine = bal;
