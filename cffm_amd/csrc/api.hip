@@ -102,7 +102,7 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
             out->w0pack_floats = 2 * (int64_t)(2 * g.F) * (g.Pp / 16) * 1024;
             out->w0pack = take(out->w0pack_floats * 4);
             if (g.live > 1 && g.act != CFFM_ACT_GELU)        // relu mask of C[0] (gelu's derivative needs the value)
-                out->relu0 = take(b * (g.D / 2) * (g.D / 2) * (g.Pp / 16) * 2);
+                out->relu0 = take(relu_mask_off(g, b, g.live - 1));       // masks of C_0 .. C_{live-2}
         }
     }
     out->bytes = o;

@@ -88,6 +88,16 @@ static inline bool conv0_fact_tile_ok(const Geo& g) {
 // the tiled layer-0 input gradient that reads the filter as pre-packed MFMA fragments (ws.w0pack)
 static inline bool conv0_tile_dgrad2_ok(const Geo& g) { return conv0_fact_tile_ok(g) && g.D / 2 <= 32 && g.F <= 32; }
 static inline bool conv0_tile_fwd_ok(const Geo& g) { return conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS; }
+// ws.relu0: relu masks of C_0 .. C_{live-2} of the wide shapes, one after the other ([rows of C_l][Pp/16] 16-bit words each)
+static inline int64_t relu_mask_bytes(const Geo& g, int64_t B, int l) {
+    const int64_t S = g.D >> (l + 1);
+    return (B * S * S * (g.Pp / 16) * 2 + 255) / 256 * 256;
+}
+static inline int64_t relu_mask_off(const Geo& g, int64_t B, int l) {
+    int64_t o = 0;
+    for (int k = 0; k < l; ++k) o += relu_mask_bytes(g, B, k);
+    return o;
+}
 // column tiles of 16 -> column blocks of NT tiles (NT in {1,2,3,4,6,8}) of the implicit-GEMM kernels
 static inline void pick_nt(int tiles, int* nblk, int* NT) {
     int nb = (tiles + 7) / 8;

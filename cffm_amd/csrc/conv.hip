@@ -191,7 +191,7 @@ struct ConvArgs {
     int idxM = 0;
     float* pool = nullptr;          // wide shapes: partial sum pools of act(out), [B][So][pool_np] (pool_partials(), common.hpp)
     int pool_np = 0;
-    uint16_t* relu = nullptr;       // tiled layer-0 forward: bit mask of out > 0, [B*So*So][Pp/16] 16-bit words (ws.relu0)
+    uint16_t* relu = nullptr;       // wide shapes (tiled layer-0 forward, conv_fwd_kernel): bit mask of out > 0, [B*So*So][Pp/16] 16-bit words (ws.relu0)
 };
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
@@ -281,17 +281,28 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
     const int pact = GEN ? CFFM_ACT_RELU : a.act;              // (the pools apply self.activation to the stored relu output, :387)
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
+        unsigned long long mine = 0;                           // relu mask (a.relu): lane (kk, r = 4*(nt & 3) + j) keeps the ballot of (nt, j)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (nt >= nvalid) continue;
-            const int n = n0 + nt * 16 + r;
-            const float bv = a.bias[n];
+            if (nt < nvalid) {
+                const int n = n0 + nt * 16 + r;
+                const float bv = a.bias[n];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
-                const float c = fmaxf(acc[rm][nt][j] + bv, 0.f);                       // CFFM.py:478
-                if (m < a.Mtot) a.out[m * Pp + n] = c;
-                psum[rm][j] += act_pos(c, a.act);              // padded channels: zero filter and bias -> act(0) = 0
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
+                    const float c = fmaxf(acc[rm][nt][j] + bv, 0.f);                       // CFFM.py:478
+                    if (m < a.Mtot) a.out[m * Pp + n] = c;
+                    psum[rm][j] += act_pos(c, a.act);              // padded channels: zero filter and bias -> act(0) = 0
+                    if (!GEN) {
+                        const unsigned long long bal = __ballot(c > 0.f);   // bits 16kk..16kk+15: the 16 channels of row (kk, j)
+                        if (r == 4 * (nt & 3) + j) mine = bal;
+                    }
+                }
+            }
+            if (!GEN && a.relu != nullptr && ((nt & 3) == 3 || nt == NT - 1)) {   // four column tiles collected: one 2-byte store per lane
+                const int ntw = (nt & ~3) + (r >> 2);
+                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + (r & 3);
+                if (ntw <= nt && ntw < nvalid && m < a.Mtot) a.relu[m * (Pp >> 4) + (n0 >> 4) + ntw] = (uint16_t)(mine >> (16 * kk));
             }
         }
     }
@@ -3948,7 +3959,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     a.Mtot = layer_rows(g, B, l, &a.lgSo);
     a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
     if (wl.pool_np[l] > 0) { a.pool = (float*)(w + wl.pool[l]); a.pool_np = wl.pool_np[l]; }   // wide shapes: the epilogue leaves the pool partials
-    if (l == 0 && wl.relu0 > 0) a.relu = (uint16_t*)(w + wl.relu0);   // ... and the relu mask of C_0 for the input gradient of layer 1
+    if (wl.relu0 > 0 && l + 1 < g.live) a.relu = (uint16_t*)(w + wl.relu0 + relu_mask_off(g, B, l));   // ... and the relu mask of C_l for the input gradient of layer l+1
     int nblk, NT;
     int rc = 0;
     if (g.Pp <= 64) {                       // tap-split path: one wave per filter tap, no K loop
@@ -4180,9 +4191,10 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         a.Cprev = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dt1 = (const float*)(w + wl.dt1);
         a.dprev = (float*)(w + (l == 0 ? wl.dEo : wl.dC[l - 1]));
-        {   // layer 1 of the wide shapes reads the relu mask the tiled layer-0 forward left (1/32 of the bytes of C_0)
+        {   // wide shapes: the relu mask the forward of layer l-1 left (1/32 of the bytes of C_{l-1})
             const char* oldfwd = getenv("CFFM_TILE_FWD");
-            if (l == 1 && wl.relu0 > 0 && !(oldfwd && oldfwd[0] == '1') && !getenv("CFFM_DGRAD_NO_MASK")) a.relu = (const uint16_t*)(w + wl.relu0);
+            if (l >= 1 && wl.relu0 > 0 && !(l == 1 && oldfwd && oldfwd[0] == '1') && !getenv("CFFM_DGRAD_NO_MASK"))
+                a.relu = (const uint16_t*)(w + wl.relu0 + relu_mask_off(g, B, l - 1));
         }
         a.Mtot = layer_rows(g, B, l, &a.lgSo);
         a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;

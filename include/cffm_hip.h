@@ -108,9 +108,10 @@ typedef struct cffm_ws_layout {
                                                fragments for the input-gradient kernel (rebuilt from theta by every backward pass;
                                                0 = not used)                                                                        */
     int64_t w0pack_floats;
-    int64_t relu0;                          /* wide shapes with the tiled layer 0: one bit per element of C[0], set where C[0] > 0
-                                               (16-bit words: [B*S_0*S_0][Pp/16]), written by the layer-0 forward and read by the
-                                               input gradient of layer 1 instead of C[0] itself (0 = not used)                     */
+    int64_t relu0;                          /* wide shapes with the tiled layer 0: one bit per element of C[0] .. C[live-2], set where
+                                               C[l] > 0 (16-bit words, [B*S_l*S_l][Pp/16] per layer, one layer after the other), written
+                                               by the forward of layer l and read by the input gradient of layer l+1 instead of C[l]
+                                               itself (0 = not used)                                                               */
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
