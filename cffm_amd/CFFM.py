@@ -74,7 +74,7 @@ class CFFM(object):
     def __init__(self, features_M, pretrain_flag, save_file, inner_dims, outer_dims, loss_type, epoch, batch_size,
                  learning_rate, lamda_bilinear, keep, optimizer_type, batch_norm, verbose, tensorboard, num_field,
                  linear_att, att_dim, lamda_att, inner_conv, gamma_inner, outer_conv, beta_outer,
-                 activation_function, random_seed=2021):
+                 activation_function, random_seed=2021, batch_rng=None):
         self.batch_size = batch_size
         self.learning_rate = learning_rate
         self.inner_dims = inner_dims
@@ -125,6 +125,11 @@ class CFFM(object):
         self.engine = None
         self._packed = {}
         self.examples_per_sec = []
+        # Source of the random block starts (CFFM.py:561 draws them from the unseeded process-global np.random; SURVEY A.6
+        # Q9: "behind an injectable RNG").  Anything with numpy's randint(low, high, size=None) works; the default IS the
+        # global np.random, so an unpinned run behaves like the reference.  batch_starts keeps the draws, one array per epoch.
+        self.batch_rng = np.random if batch_rng is None else batch_rng
+        self.batch_starts = []
         # multi-GPU (set by build_graph under torch.distributed): one process per GPU, data parallel over the batch
         self.world, self.rank, self._dp = 1, 0, None
 
@@ -241,15 +246,17 @@ class CFFM(object):
                 ids, y = ids[pt].contiguous(), y[pt].contiguous()
                 order = order[perm]
                 total_batch = int(n / self.batch_size)
-                # CFFM.py:561: one unseeded np.random.randint per step.  Drawn for the whole epoch at once (the same stream
-                # as one call per step); under torch.distributed rank 0's draws are everyone's, so that the ranks cut
-                # their slices out of the SAME global batch.
-                starts = np.random.randint(0, n - self.batch_size, size=total_batch)
+                # CFFM.py:561: one np.random.randint per step, from self.batch_rng (the unseeded global np.random unless the
+                # caller injected one).  Drawn for the whole epoch at once (the same stream as one call per step); under
+                # torch.distributed rank 0's draws are everyone's, so that the ranks cut their slices out of the SAME
+                # global batch.
+                starts = self.batch_rng.randint(0, n - self.batch_size, size=total_batch)
                 if self.world > 1:
                     import torch.distributed as dist
                     st = torch.from_numpy(starts.astype(np.int64)).to(ids.device)
                     dist.broadcast(st, src=0)
                     starts = st.cpu().numpy()
+                self.batch_starts.append(np.asarray(starts, dtype=np.int64))
                 per = self.batch_size // self.world
                 for start in starts:
                     start = int(start)
@@ -338,7 +345,7 @@ class CFFM(object):
     def get_random_block_from_data(self, data, batch_size):
         """A block from a random start, filled forward over rows as long as the start row, then BACKWARD from the
         same start (which re-adds the start row when the forward fill stopped short) - CFFM.py:560-581."""
-        start_index = np.random.randint(0, len(data['Y']) - batch_size)
+        start_index = self.batch_rng.randint(0, len(data['Y']) - batch_size)
         want = len(data['X'][start_index])
         X, Y = [], []
         for step in (1, -1):

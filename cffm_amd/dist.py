@@ -122,13 +122,7 @@ class DataParallelStep(object):
             st = {'ids': ids.clone(), 'y': y.clone(), 'calls': 0, 'graph': None, 'loss': None, 'ws_gen': -1}
             self._graphs[key] = st
         st['calls'] += 1
-        gen = getattr(self.c, 'ws_generation', 0)
-        if st['graph'] is not None and st['ws_gen'] != gen:
-            # the engine re-allocated its workspace since the capture (a larger batch, evaluate()'s 8192-row blocks): the
-            # captured kernels still point at the old buffer, which the engine keeps alive while it is pinned.  Drop the
-            # graph and capture again against the current buffer.
-            st['graph'] = None
-            self._unpin()
+        self._drop_stale_graphs()
         if st['graph'] is None:
             if st['calls'] <= 2:                 # warm-up: workspaces, communicators and kernel attributes get created eagerly
                 return self._eager(ids, y)
@@ -142,6 +136,7 @@ class DataParallelStep(object):
             st['ws_gen'] = getattr(self.c, 'ws_generation', 0)
             if hasattr(self.c, 'pin_workspace'):
                 self.c.pin_workspace()           # from now on an outgrown workspace is retired, not freed
+                st['pinned'] = True
             g.replay()                           # capturing only records: run this batch now
             return st['loss']
         st['ids'].copy_(ids)
@@ -149,10 +144,23 @@ class DataParallelStep(object):
         st['graph'].replay()
         return st['loss']
 
-    def _unpin(self):
-        if hasattr(self.c, 'unpin_workspace'):
-            torch.cuda.synchronize()             # no replay of the dropped graph is still running on the old buffer
-            self.c.unpin_workspace()
+    def _drop_stale_graphs(self):
+        """The engine re-allocated its workspace since some capture (a larger batch, evaluate()'s 8192-row blocks): those
+        captured kernels still point at the old buffer, which the engine keeps alive while its generation is pinned.  EVERY
+        graph of an older generation is dropped here - also the ones of batch shapes that may never be called again - so
+        that the outgrown buffer (~50 GB at F32 D64 B8192) is freed now; a dropped graph is captured again, against the
+        current buffer, at the next call of its shape."""
+        gen = getattr(self.c, 'ws_generation', 0)
+        stale = [st for st in self._graphs.values() if st['graph'] is not None and st['ws_gen'] != gen]
+        if not stale:
+            return 0
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()             # no replay of a dropped graph is still running on the old buffer
+        for st in stale:
+            st['graph'] = None
+            if st.pop('pinned', False):
+                self.c.unpin_workspace(st['ws_gen'])
+        return len(stale)
 
 
 def shard_of(ids, world):

@@ -28,6 +28,50 @@ def _ptr(t):
     return t.data_ptr() if t is not None else 0
 
 
+class WorkspacePool(object):
+    """ONE grow-only byte buffer plus the bookkeeping that captured HIP graphs need.
+
+    A captured graph has the buffer's address baked into its kernel arguments.  Every re-allocation starts a new
+    GENERATION; ``pin()`` says "a graph now references the current generation" and returns that generation, ``unpin(gen)``
+    says that graph was dropped or re-captured.  A buffer that is outgrown while its generation is pinned is RETIRED (kept
+    alive) and freed the moment the last pin of ITS generation goes - not when the pin count of all generations reaches 0:
+    with two captured batch shapes one regrowth used to leave a ~50 GB buffer (F32 D64 B8192) alive for as long as any
+    graph existed.  ``alloc(nbytes)`` is the allocator (torch.empty on the device; tests pass a host one)."""
+
+    def __init__(self, alloc):
+        self._alloc = alloc
+        self.buf = None
+        self.generation = 0
+        self.pins = {}          # generation -> captured graphs that reference that generation's buffer
+        self.retired = {}       # generation -> outgrown buffer those graphs may still replay against
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            if self.buf is not None:
+                if self.pins.get(self.generation, 0) > 0:
+                    self.retired[self.generation] = self.buf
+                self.generation += 1
+            self.buf = None                               # release (unless retired) before allocating the larger one
+            self.buf = self._alloc(nbytes)
+        return self.buf
+
+    def pin(self):
+        self.pins[self.generation] = self.pins.get(self.generation, 0) + 1
+        return self.generation
+
+    def unpin(self, generation):
+        left = self.pins.get(generation, 0) - 1
+        if left > 0:
+            self.pins[generation] = left
+        else:
+            self.pins.pop(generation, None)
+            self.retired.pop(generation, None)            # the last graph of that generation is gone: free its buffer
+
+    def retired_bytes(self):
+        return sum(int(b.numel()) for b in self.retired.values())
+
+
 class HipEngine(object):
     def __init__(self, cfg, params=None, seed=2021, device='cuda:0', table_seed=None):
         if not torch.cuda.is_available():
@@ -40,10 +84,7 @@ class HipEngine(object):
         self.shape = hip.make_shape(cfg)
         self.tl = hip.theta_layout(self.shape)
         self._ws = {}
-        self._ws_buf = None
-        self.ws_generation = 0                        # bumped whenever the workspace buffer is re-allocated
-        self._ws_pins = 0                             # captured graphs that reference the workspace (pin_workspace)
-        self._ws_retired = []                         # outgrown buffers such a graph may still replay against
+        self._pool = WorkspacePool(lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=self.device))
         self._eval_scratch = None
         self._flat_dirty = False                      # dense-image route: the image is zero on entry, zero on exit
         self._host_only = {}
@@ -221,9 +262,8 @@ class HipEngine(object):
         at F32 D64 B8192 it is ~50 GB, so one copy per distinct B would exhaust HBM within a few steps.
 
         A captured HIP graph (DataParallelStep(use_graph=True)) has the buffer's address baked into its kernel arguments:
-        while ``pin_workspace()`` is in effect a buffer that is outgrown is RETIRED (kept alive), not freed, and
-        ``ws_generation`` changes so that the owner of the graph re-captures against the new buffer and then calls
-        ``release_retired()``."""
+        see WorkspacePool - an outgrown buffer is kept alive exactly as long as a graph captured against it is pinned, and
+        ``ws_generation`` changes so that the owner of the graph re-captures against the new buffer."""
         B = int(B)
         wl = self._ws.get(B)
         if wl is None:
@@ -231,14 +271,11 @@ class HipEngine(object):
                 self._ws = {k: v for k, v in self._ws.items() if not isinstance(k, int)}
             wl = hip.ws_layout(self.shape, B)
             self._ws[B] = wl
-        if self._ws_buf is None or self._ws_buf.numel() < int(wl.bytes):
-            if self._ws_buf is not None:
-                self.ws_generation += 1
-                if self._ws_pins > 0:
-                    self._ws_retired.append(self._ws_buf)      # a graph may still replay against it
-            self._ws_buf = None                           # release (unless retired) before allocating the larger one
-            self._ws_buf = torch.empty(int(wl.bytes), dtype=torch.uint8, device=self.device)
-        return self._ws_buf, wl
+        return self._pool.get(wl.bytes), wl
+
+    @property
+    def ws_generation(self):
+        return self._pool.generation
 
     def reserve_workspace(self, B):
         """Grow the workspace to what a batch of B rows needs (e.g. evaluate()'s 8192-row blocks) BEFORE a graph is
@@ -246,17 +283,12 @@ class HipEngine(object):
         return self.workspace(B)[0]
 
     def pin_workspace(self):
-        """A graph that references the current workspace buffer exists from now on (see workspace())."""
-        self._ws_pins += 1
+        """A graph that references the current workspace buffer exists from now on; returns the generation to unpin."""
+        return self._pool.pin()
 
-    def unpin_workspace(self):
-        self._ws_pins = max(0, self._ws_pins - 1)
-        if self._ws_pins == 0:
-            self._ws_retired = []
-
-    def release_retired(self):
-        """Every graph that referenced a retired buffer has been dropped or re-captured."""
-        self._ws_retired = []
+    def unpin_workspace(self, generation):
+        """The graph pinned at `generation` was dropped or re-captured."""
+        self._pool.unpin(generation)
 
     def ws_tensor(self, B, member, shape, dtype=torch.float32, index=None):
         """View of one workspace intermediate (for the parity tests)."""

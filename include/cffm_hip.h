@@ -149,19 +149,30 @@ int cffm_inner_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t 
 /* its gradient: ws.dout, ws.Ei -> ws.dEi, gpart slabs of inner_cw/inner_cb/inner_dw/inner_db */
 int cffm_inner_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
 
-/* outer product fused with conv layer 0 (CFFM.py:355-367 + :385-386 for i = 0): ws.Eo -> ws.C[0] */
+/* STAGE CONTRACT FOR WIDE SHAPES (Pp = ceil16(F*(F-1)/2) > 64, every activation but gelu).  The forward stages leave two
+ * side products in the workspace and the later stages CONSUME THOSE instead of re-reading the conv outputs:
+ *   ws.pool[l]   row-sum partials of C[l] (CFFM.py:381, :390) written by the epilogue of cffm_outer_conv0_fwd (l = 0) and
+ *                cffm_conv_fwd (l >= 1); cffm_head_fwd sums THESE and does not read ws.C[*];
+ *   ws.relu0     relu bit masks of C[0] .. C[live-2], one 16-bit word per (pixel, 16 channels), written by the same
+ *                epilogues; cffm_conv_bwd (l >= 1) reads the mask of C[l-1] in place of ws.C[l-1].
+ * A caller that writes ws.C itself, or runs another forward on the same workspace between a forward stage and its consumer,
+ * must re-run cffm_outer_conv0_fwd / cffm_conv_fwd for that layer first: stale pools / masks are not detected.  The narrow
+ * shapes (Pp <= 64) and gelu keep the contract written at each entry point below (pools and masks are swept from ws.C). */
+/* outer product fused with conv layer 0 (CFFM.py:355-367 + :385-386 for i = 0): ws.Eo -> ws.C[0] (wide: + ws.pool[0], ws.relu0) */
 int cffm_outer_conv0_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
 /* ws.dC[0], ws.dt1, ws.Eo -> ws.dEo, gpart slabs of conv_w[0]/conv_b[0] */
 int cffm_outer_conv0_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
 
-/* conv layer l >= 1 (CFFM.py:385-387): ws.C[l-1] -> ws.C[l] */
+/* conv layer l >= 1 (CFFM.py:385-387): ws.C[l-1] -> ws.C[l] (wide: + ws.pool[l], and the relu mask of C[l] for l <= live-2) */
 int cffm_conv_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, int32_t layer, void *stream);
-/* ws.dC[l], ws.C[l-1], ws.dt1 -> ws.dC[l-1], gpart slabs of conv_w[l]/conv_b[l] */
+/* ws.dC[l], ws.C[l-1], ws.dt1 -> ws.dC[l-1], gpart slabs of conv_w[l]/conv_b[l].  Wide shapes: the input gradient takes the
+ * relu mask of C[l-1] from ws.relu0 (see the stage contract above); the weight gradient still reads ws.C[l-1]. */
 int cffm_conv_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, int32_t layer, void *stream);
 
 /* sum pooling + concat + dense heads + first-order term + add_n (CFFM.py:381, :390-396, :409-453):
  * ws.C[*], ws.Eo, ws.fb, ws.inner_out -> ws.t1, ws.h1, ws.att, ws.out; when y != NULL also ws.sqerr and
- * scalars[0] = sum of per-example loss terms over the B local rows. */
+ * scalars[0] = sum of per-example loss terms over the B local rows.  Wide shapes: ws.pool[*] in place of ws.C[*] (see the
+ * stage contract above). */
 int cffm_head_fwd(const cffm_shape_t *s, const float *theta, void *ws, const float *y, int32_t B, void *stream);
 /* loss gradient (CFFM.py:493) and the head's backward: ws.out, y, scalars[3] (the loss-term sum over
  * the GLOBAL batch of B_global rows) -> ws.dout, ws.dt1, ws.dfb, ws.dC[live-1], gpart slabs of the

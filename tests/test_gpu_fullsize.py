@@ -337,15 +337,16 @@ def test_graph_replay_survives_a_workspace_regrowth(nccl_world1):
         assert float(lg) == float(le), i
         if i == 3:                                    # a graph exists by now (captured at the third call)
             st = next(iter(dp_g._graphs.values()))
-            assert st['graph'] is not None and eng_g._ws_pins == 1
+            assert st['graph'] is not None and eng_g._pool.pins == {eng_g.ws_generation: 1}
             gen = eng_g.ws_generation
-            old = eng_g._ws_buf
+            old = eng_g._pool.buf
             pg, pe = eng_g.predict(big), eng_e.predict(big)          # outgrows the captured workspace
             torch.cuda.synchronize()
-            assert eng_g.ws_generation == gen + 1 and eng_g._ws_retired and eng_g._ws_retired[0] is old
+            assert eng_g.ws_generation == gen + 1 and eng_g._pool.retired[gen] is old
             assert torch.equal(pg, pe)
     st = next(iter(dp_g._graphs.values()))
     assert st['graph'] is not None and st['ws_gen'] == eng_g.ws_generation      # re-captured against the new buffer
+    assert not eng_g._pool.retired and eng_g._pool.pins == {eng_g.ws_generation: 1}  # and the outgrown buffer is freed
     a, b = eng_g.export_params(), eng_e.export_params()
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -7,60 +7,11 @@ import torch
 
 from cffm_amd.spec import CFFMConfig, init_params
 from oracle import cffm_oracle as orc
+from oracle.parity import (REL_FLOOR, REL_TOL, TOL, WORST, adopt_device_kinks, check_backward_stages,  # noqa: F401
+                           check_gather_inner_fwd_wide, close, dense_grad_slack, dout_slack, inner_kink_slack,
+                           oracle_dense_grads, pad_channels, to64)
 
 pytestmark = pytest.mark.gpu
-
-TOL = 1e-5
-REL_FLOOR = 1e-2          # elements above REL_FLOOR * max|ref| must also be within REL_TOL relative.  Consistent with tier 1:
-                          # rms <= max, so tol * (|ref| + rms) <= 1e-5 * 101 |ref| ~ 1e-3 |ref| for |ref| >= 1e-2 max; the tier
-                          # therefore binds exactly the <= 1 % of elements tier 1 lets through
-REL_TOL = 1e-3
-WORST = {}                # name -> worst (|err| / bound) seen, printed at the end of the session (see conftest)
-
-
-def close(got, ref, name, tol=TOL, ignore=None, extra=None):
-    """Element-wise, genuinely relative bound  B = tol * (|ref| + rms(ref)) [+ extra]:
-
-      tier 1   at least 99 % of the elements within B
-      tier 2   EVERY element within 4 * B
-      tier 3   every element above 1e-2 * max|ref| within 1e-3 relative
-
-    An fp32 sum of n terms carries an absolute error that scales with the magnitude of its terms, i.e. with the typical
-    size of the tensor (its rms), not with the element itself - hence |ref| + rms, NOT tol * max|ref| (which would let
-    an element 1000x below the maximum be 1 % wrong).  Rounding error is statistical: a value that went through ~10
-    chained fp32 contractions (forward conv stack, head, backward stack) typically sits at 2-5e-6 of that scale and the
-    worst of a million elements at ~1e-5 (numpy's own fp32 evaluation of the oracle lands at 1.2-2.1e-5 * rms on the
-    ill-conditioned outputs of 'f20-d32-b300-selu'), hence the two tiers instead of one loosened tolerance.  ``extra``
-    adds a bound propagated from an upstream tolerance (optimizer amplification, dL/dout cancellation; see the callers).
-    The worst err / B per tensor is recorded in WORST and written to gpurun_out/parity_worst.json."""
-    got = np.asarray(got, dtype=np.float64)
-    ref = np.asarray(ref, dtype=np.float64)
-    assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    if ref.size == 0:
-        return
-    amax = max(float(np.abs(ref).max()), 1e-30)
-    rms = max(float(np.sqrt(np.mean(ref * ref))), 1e-30)
-    err = np.abs(got - ref)
-    bound = tol * (np.abs(ref) + rms)
-    if extra is not None:
-        bound = bound + extra
-    big = np.abs(ref) >= REL_FLOOR * amax
-    rel_bound = REL_TOL * np.abs(ref) + (extra if extra is not None else 0.0)
-    over1 = err > bound
-    bad = (err > 4.0 * bound) | (big & (err > rel_bound))
-    if ignore is not None:
-        over1 &= ~ignore
-        bad &= ~ignore
-    allowed = int(np.ceil(0.01 * ref.size)) if ref.size > 1 else 0
-    ratio = float((err / bound).max())
-    WORST[name] = max(WORST.get(name, 0.0), ratio)
-    rel_big = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
-    assert not bad.any() and int(over1.sum()) <= allowed, \
-        '%s: %d/%d beyond tol (%d allowed), %d beyond the hard bound, max err %.3e (rms %.3e, max %.3e), worst err/bound ' \
-        '%.2f, worst rel err above floor %.2e at %s' % (name, int(over1.sum()), bad.size, allowed, int(bad.sum()),
-                                                       float(err.max()), rms, amax, ratio, rel_big,
-                                                       np.unravel_index(int((err / bound).argmax()), err.shape))
-
 
 CASES = {
     'tiny-relu': dict(M=60, F=4, K=8, D=8, act='relu', B=5),
@@ -141,116 +92,9 @@ def make_case(name, seed=0, trained_like=True):
     return cfg, p32, X, y
 
 
-def to64(p):
-    return {k: np.asarray(v, dtype=np.float64) for k, v in p.items()}
-
-
 def engine_for(cfg, p32):
     from cffm_amd.engine import HipEngine
     return HipEngine(cfg, params=p32)
-
-
-def oracle_dense_grads(p64, X, y, cfg, hook=None):
-    """Oracle gradients of one step in dense form (table rows scatter-added)."""
-    out, c = orc.forward(p64, X, cfg)
-    if hook is not None:
-        hook(c)
-    _, dout = orc.loss_and_grad(out, y.astype(np.float64), cfg, p64)
-    g = orc.backward(p64, c, dout, cfg)
-    ids = X.reshape(-1)
-    dense = {k: np.asarray(v) for k, v in g.items() if not k.startswith('d_') and not k.startswith('_')}
-    for name, key in (('inner_embeddings', 'd_inner_rows'), ('outer_embeddings', 'd_outer_rows'),
-                      ('feature_bias', 'd_bias_rows')):
-        if key in g:
-            t = np.zeros(p64[name].shape)
-            np.add.at(t, ids, g[key].reshape(ids.shape[0], -1))
-            dense[name] = t
-    return dense
-
-
-def adopt_device_kinks(cfg, eng, B, cache):
-    """relu is discontinuous in its gradient: where the float64 pre-activation of a conv layer sits within
-    fp32 rounding of 0, relu'(z) = 0 and relu'(z) = 1 are both correct fp32 answers, and that one choice
-    moves every gradient downstream of it by O(1) terms.  For exactly those elements (|z| < 1e-5 * max|z|)
-    the oracle adopts the decision the device took; everything else stays the oracle's own."""
-    n = 0
-    for l in range(cfg.live_layers):
-        z = cache['zs'][l]
-        kink = np.abs(z) < 1e-5 * np.abs(z).max()
-        assert kink.sum() <= max(2, 1e-3 * kink.size)
-        if kink.any():
-            S = cfg.D >> (l + 1)
-            Cg = eng.ws_tensor(B, 'C', (B, S, S, eng.tl.Pp), index=l).cpu().numpy()[..., :cfg.P].astype(np.float64)
-            r = cache['rs'][l]
-            r[kink] = np.where(Cg[kink] > 0, np.maximum(r[kink], 1e-30), 0.0)
-            n += int(kink.sum())
-    return n
-
-
-def pad_channels(a, Pp):
-    out = np.zeros(a.shape[:-1] + (Pp,), dtype=a.dtype)
-    out[..., :a.shape[-1]] = a
-    return out
-
-
-def inner_kink_slack(p64, cache, dout, cfg):
-    """The inner branch (CFFM.py:327-332) has two discontinuous gradients: relu'(z) of the 1x2 conv at z = 0 and the
-    arg-max of the 2-wide max-pool on a tie.  Its intermediates are never written to memory by the HIP path (one pass
-    in LDS), so the device's decision cannot be read back as adopt_device_kinks does for the conv stack.  Where the
-    float64 value sits within fp32 rounding of the discontinuity (|z| < 1e-5 max|z|, |x0 - x1| < 1e-6 max|x|), BOTH
-    decisions are correct fp32 answers: the slack returned here is |gradient(decision A) - gradient(decision B)| per
-    element, added to the bound of the three gradients that depend on it.  Empty when no element is that close."""
-    if not cfg.inner_conv:
-        return {}
-    import copy
-    z, x = cache['z'], cache['x']
-    kink = np.abs(z) < 1e-5 * np.abs(z).max()
-    x0, x1 = x[:, :, 0::2], x[:, :, 1::2]
-    tie = (np.abs(x0 - x1) < 1e-6 * np.abs(x).max()) & (x0 != x1)
-    if not kink.any() and not tie.any():
-        return {}
-    icfg = copy.copy(cfg)
-    icfg.outer_conv = 0
-    sides = []
-    for side in (0, 1):
-        c2 = dict(cache)
-        r = cache['r'].copy()
-        r[kink] = 0.0 if side == 0 else 1e-30
-        first = x0 >= x1
-        first[tie] = bool(side)
-        c2['r'], c2['first_override'] = r, first
-        sides.append(orc.backward(p64, c2, dout, icfg))
-    print('inner branch: %d relu kinks, %d max-pool near-ties -> two-sided slack' % (int(kink.sum()), int(tie.sum())))
-    return {k: np.abs(np.asarray(sides[0][k]) - np.asarray(sides[1][k]))
-            for k in ('inner_layer_conv_weight_0', 'inner_layer_conv_bias_0', 'd_inner_rows')}
-
-
-def dense_grad_slack(p64, cache, dsl, cfg):
-    """Slack of the batch-summed (dense) gradients that follows from the slack dsl of dL/dout: every gradient is LINEAR in
-    dL/dout, so an error e_b (|e_b| <= dsl_b, arbitrary sign) moves gradient k by sum_b e_b * J_bk.  The rigorous bound
-    sum_b dsl_b |J_bk| needs every per-example Jacobian; the errors of `out` behave as independent rounding noise, so the
-    scale is probed instead: two oracle backward passes with dL/dout := (random signs) * dsl, element-wise maximum, times
-    4, plus twice the rms of the probe over the tensor.  Negligible whenever `out` is well-conditioned (dsl ~ 1e-5 dout);
-    it matters for heads that cancel heavily (t1 ~ 50x out in 'f20-d32-b300-selu')."""
-    rng = np.random.default_rng(0)
-    probe = {}
-    for _ in range(2):
-        g2 = orc.backward(p64, cache, rng.choice([-1.0, 1.0], size=dsl.shape) * dsl, cfg)
-        for k, v in g2.items():
-            if not k.startswith('_') and not k.startswith('d_'):
-                probe[k] = np.maximum(probe.get(k, 0.0), np.abs(np.asarray(v)))
-    return {k: 4.0 * v + 2.0 * float(np.sqrt(np.mean(v * v))) for k, v in probe.items()}
-
-
-def dout_slack(out_ref, y, cfg, p64):
-    """dL/dout is computed from the device's own `out`, which is held to 1e-5 * (|out| + rms): where out ~ y the
-    difference out - y cancels, so the bound on dout is that output tolerance propagated through the loss."""
-    d = TOL * (np.abs(out_ref) + float(np.sqrt(np.mean(out_ref * out_ref))))
-    y64 = y.astype(np.float64)
-    _, g0 = orc.loss_and_grad(out_ref, y64, cfg, p64)
-    _, g1 = orc.loss_and_grad(out_ref + d, y64, cfg, p64)
-    _, g2 = orc.loss_and_grad(out_ref - d, y64, cfg, p64)
-    return np.maximum(np.abs(g1 - g0), np.abs(g2 - g0))
 
 
 @pytest.mark.parametrize('name', LIGHT)
@@ -290,89 +134,16 @@ WIDE_NM = ['f32-d64-relu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-
 
 @pytest.mark.parametrize('name', WIDE_NM)
 def test_gather_inner_fwd_wide(name):
-    """cffm_gather_inner_fwd on its own: the three lookups fused with the inner branch, the s0 pool and the first-order inputs.
-    ws.Ei / ws.Eo must stay untouched (poisoned beforehand); fb is a copy (exact), inner_out and s0 against the oracle; then the
-    whole non-materialising forward (cffm_predict) with the workspace rows still poisoned."""
+    """cffm_gather_inner_fwd on its own (oracle.parity.check_gather_inner_fwd_wide: rows never materialised, fb exact,
+    inner_out / s0 / keys / the whole non-materialising predict against the oracle)."""
     cfg, p32, X, y = make_case(name)
-    eng = engine_for(cfg, p32)
-    assert eng.gather_inner_fwd_ok()
-    B = X.shape[0]
-    out_ref, c = orc.forward(to64(p32), X, cfg)
-    ids = torch.from_numpy(X).cuda()
-    eng.workspace(B)
-    Ei, Eo = eng.ws_tensor(B, 'Ei', (B, cfg.F, cfg.K)), eng.ws_tensor(B, 'Eo', (B, cfg.F, cfg.D))
-    Ei.fill_(float('nan'))
-    Eo.fill_(float('nan'))
-    eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).fill_(float('nan'))
-    eng.gather_inner_fwd(ids)
-    torch.cuda.synchronize()
-    assert bool(torch.isnan(Ei).all()) and bool(torch.isnan(Eo).all())
-    np.testing.assert_array_equal(eng.ws_tensor(B, 'fb', (B, cfg.F)).cpu().numpy(), p32['feature_bias'][X][:, :, 0])
-    close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out (fused gather)')
-    close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy()[:, :cfg.D], c['t1'][:, :cfg.D], 's0 (fused gather)')
-    keys = eng.ws_tensor(B, 'sort_keys', (B * cfg.F,), dtype=torch.int64).cpu().numpy()
-    np.testing.assert_array_equal(keys >> 32, X.reshape(-1))
-    np.testing.assert_array_equal(keys & 0xffffffff, np.arange(B * cfg.F))
-    close(eng.predict(ids).cpu().numpy(), out_ref, 'predict (rows never materialised)')
-    assert bool(torch.isnan(Ei).all()) and bool(torch.isnan(Eo).all())
-    close(eng.ws_tensor(B, 't1', (B, 2 * cfg.D - 2)).cpu().numpy(), c['t1'], 't1')
+    check_gather_inner_fwd_wide(cfg, p32, X, y, engine_for(cfg, p32))
 
 
 @pytest.mark.parametrize('name', list(CASES))
 def test_backward_stages(name):
     cfg, p32, X, y = make_case(name)
-    eng = engine_for(cfg, p32)
-    B = X.shape[0]
-    p64 = to64(p32)
-    out_ref, c = orc.forward(p64, X, cfg)
-    L, dout = orc.loss_and_grad(out_ref, y.astype(np.float64), cfg, p64)
-    ids = torch.from_numpy(X).cuda()
-    yt = torch.from_numpy(y).cuda()
-    eng.forward(ids, yt)
-    torch.cuda.synchronize()
-    Pp = eng.tl.Pp
-    if name in HEAVY:      # the forward intermediates of the heavy case are checked here (one oracle pass for both)
-        for l in range(cfg.live_layers):
-            S = cfg.D >> (l + 1)
-            close(eng.ws_tensor(B, 'C', (B, S, S, Pp), index=l).cpu().numpy(), pad_channels(c['rs'][l], Pp), 'C[%d]' % l)
-        close(eng.ws_tensor(B, 'inner_out', (B,)).cpu().numpy(), c['inner_out'], 'inner_out')
-        close(eng.ws_tensor(B, 'out', (B,)).cpu().numpy(), out_ref, 'out')
-    if cfg.outer_conv:
-        n_kink = adopt_device_kinks(cfg, eng, B, c)
-        print('%s: %d relu decisions adopted from the device' % (name, n_kink))
-    g = orc.backward(p64, c, dout, cfg)
-    eng.backward(yt, B)
-    torch.cuda.synchronize()
-    sc = eng.ws_tensor(B, 'scalars', (16,)).cpu().numpy()
-    close(sc[1:2], [L], 'loss')
-    dsl = dout_slack(out_ref, y, cfg, p64)
-    close(eng.ws_tensor(B, 'dout', (B,)).cpu().numpy(), dout, 'dout', extra=dsl)
-    slack = inner_kink_slack(p64, c, dout, cfg)
-    # every per-example gradient is dL/dout_b times something that does not depend on dL/dout: the relative slack of
-    # dout_b (out_b - y_b cancels where the model fits) carries over to example b's rows of these tensors unchanged
-    rel_b = dsl / np.maximum(np.abs(dout), 1e-300)
-    per_ex = lambda ref: rel_b.reshape((B,) + (1,) * (ref.ndim - 1)) * np.abs(ref)
-    if cfg.outer_conv:
-        close(eng.ws_tensor(B, 'dt1', (B, 2 * cfg.D - 2)).cpu().numpy(), g['_dt1'], 'dt1', extra=per_ex(g['_dt1']))
-        for l in range(cfg.live_layers - 1, -1, -1):
-            S = cfg.D >> (l + 1)
-            got = eng.ws_tensor(B, 'dC', (B, S, S, Pp), index=l).cpu().numpy()
-            ref = pad_channels(g['_dC'][l], Pp)
-            close(got, ref, 'dC[%d]' % l, extra=per_ex(ref))
-        close(eng.ws_tensor(B, 'dEo', (B, cfg.F, cfg.D)).cpu().numpy(), g['d_outer_rows'], 'dEo', extra=per_ex(g['d_outer_rows']))
-    if cfg.inner_conv:
-        close(eng.ws_tensor(B, 'dEi', (B, cfg.F, cfg.K)).cpu().numpy(), g['d_inner_rows'], 'dEi',
-              extra=per_ex(g['d_inner_rows']) + slack.get('d_inner_rows', 0.0))
-    close(eng.ws_tensor(B, 'dfb', (B, cfg.F)).cpu().numpy(), g['d_bias_rows'], 'dfb', extra=per_ex(g['d_bias_rows']))
-    got = eng.export_grad()
-    dgs = dense_grad_slack(p64, c, dsl, cfg)
-    for k, v in got.items():
-        if k in g:
-            extra = np.asarray(dgs[k]).reshape(v.shape) + (slack[k].reshape(v.shape) if k in slack else 0.0)
-            close(v, np.asarray(g[k]).reshape(v.shape), 'grad ' + k, extra=extra)
-        else:                               # parameters of a disabled branch receive no gradient (TF skips them)
-            assert not (cfg.linear_att and cfg.inner_conv and cfg.outer_conv), k
-            assert np.all(v == 0), k
+    check_backward_stages(cfg, p32, X, y, engine_for(cfg, p32), name=name, heavy=name in HEAVY)
 
 
 TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'mltag-full', 'bookx-full', 'f32-d64-relu', 'f12-d32-nolinatt', 'b1-elu',
