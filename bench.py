@@ -107,7 +107,7 @@ def event_time_ms(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def gather_roofline(device):
+def gather_roofline(device, with_stress=False):
     """The embedding gather on the stress shape of BASELINE.json configs[3] (32 fields, dim 64, 1 M features, 8192 rows,
     uniform ids: 516 MB of tables, beyond the Infinity Cache), timed with HIP events on the stream the kernels are launched
     on (torch's current stream).  achieved = ALGORITHMIC bytes (F*(K+D+1)*4 + F*4 per example) / time.
@@ -165,10 +165,12 @@ def gather_roofline(device):
             traffic = int(json.load(fh)['gather_inner_fwd_wide_kernel']['hbm_bytes_per_launch'])
     except Exception:
         traffic, source = None, None
-    del eng, Ei, Eo, fbo, packed
+    del Ei, Eo, fbo, packed
+    stress = stress_step(eng, cfg, ids[0], B) if with_stress else None
+    del eng
     torch.cuda.empty_cache()
     rate = lambda ms: round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)
-    return {'bound': 'hbm', 'kernel': 'gather_inner_fwd_wide_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+    return stress, {'bound': 'hbm', 'kernel': 'gather_inner_fwd_wide_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
             'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms_fused * 1e3, 2),
             'note': 'product-path kernel (cffm_train_step / cffm_predict at this shape): lookups fused with the inner branch, '
@@ -176,6 +178,35 @@ def gather_roofline(device):
             'gather_packed_kernel': {'us_per_launch': round(ms_packed * 1e3, 2), 'achieved': rate(ms_packed)},
             'gather_rows_kernel': {'us_per_launch': round(ms_rows * 1e3, 2), 'achieved': rate(ms_rows)},
             'workload': 'synthetic libfm 32 fields dim 64 1M features batch 8192 uniform ids (tables 516 MB)'}
+
+
+def executed_flops_per_example(cfg):
+    """FLOPs of one train step per example AS THE KERNELS RUN IT: conv layer 0 in its factorised form (rank-1 input channels:
+    T[dh][i][x][q] = sum_{dw, j>i} E_j[2x+dw] W[dh,dw,(i,j),q] costs 8 S0 P^2, C = sum_{dh,i} E_i[2y+dh] T costs 4 F S0^2 P),
+    layers >= 1 as direct contractions, 3 contractions per layer (forward, input gradient, weight gradient); unpadded."""
+    P, D, F, live = cfg.P, cfg.D, cfg.F, cfg.Lc - 1
+    S0 = D >> 1
+    l0 = 8 * S0 * P * P + 4 * F * S0 * S0 * P
+    rest = sum(2 * (D >> (l + 1)) ** 2 * 4 * P * P for l in range(1, live))
+    return 3 * (l0 + rest)
+
+
+def stress_step(eng, cfg, ids, B):
+    """BASELINE.json configs[3] driver-timed: 1 warm-up + 3 timed cffm_train_step calls (forward + backward + Adagrad) at F32 D64
+    M = 1M B = 8192 on the engine the roofline leg built, HIP events on the launch stream."""
+    y = torch.from_numpy(synth.sample_labels(np.random.default_rng(7), B)).to(ids.device)
+    ms = event_time_ms(lambda: eng.train_step(ids, y), 3, warm=1)
+    loss = float(eng.loss_buf[0].item())
+    if not np.isfinite(loss):
+        raise SystemExit('bench.py: stress-shape loss is not finite')
+    ex_tf = executed_flops_per_example(cfg) * B / (ms * 1e-3) / 1e12
+    ref_tf = step_flops_per_example(cfg) * B / (ms * 1e-3) / 1e12
+    return {'workload': WORKLOADS['syn1m']['text'], 'steps': 3, 'warmup': 1, 'ms_per_step': round(ms, 2),
+            'examples_per_s': round(B / (ms * 1e-3), 1), 'executed_TFLOPs': round(ex_tf, 1),
+            'executed_frac_of_mfma_f32_peak': round(ex_tf / MFMA_F32_PEAK_TFLOPS, 4),
+            'reference_algorithm_TFLOPs': round(ref_tf, 1), 'loss': round(loss, 6),
+            'note': 'executed = conv layer 0 factorised (rank-1 input channels), layers >= 1 direct, 3 contractions per layer, '
+                    'unpadded; peak = 157.3 TFLOP/s dense fp32 MFMA'}
 
 
 def stage_times(eng, ids, y):
@@ -317,6 +348,13 @@ def main():
     rehearsal = bool(os.environ.get('CFFM_BENCH_REHEARSAL'))
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < max(world, 1):
+        # fewer visible GPUs than ranks: every rank sees the same count (device_count() does not initialise the GPU on this
+        # image; the parent of a self-launch never asks), so all of them leave with status 3 before any collective could hang,
+        # rank 0 says why in one line, and the launcher hands the non-zero status back
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d needs %d visible GPUs, this node shows %d\n' % (args.gpus, world, torch.cuda.device_count()))
+        raise SystemExit(3)
     use_pg = world > 1 or args.tables == 'sharded' or args.force_dp
     if use_pg:
         import torch.distributed as dist
@@ -446,7 +484,7 @@ def main():
             res['value_with_host_batching'] = round(B * nb / (time.perf_counter() - t0), 1)
             res['stage_us'] = stage_times(eng, X[0], y[0])
             del X, y
-            res['roofline'] = gather_roofline(device)
+            res['stress'], res['roofline'] = gather_roofline(device, with_stress=True)
             res['roofline']['measured_peaks'] = measured_peaks(device)
             if not args.no_cpu_baseline and not big:
                 res['cpu_baseline'] = cpu_baseline(cfg, Xh, yh)
@@ -454,7 +492,7 @@ def main():
             # N > 1: the roofline object of the dominant gather kernel again, measured on rank 0's GPU once the timed blocks are
             # over (the other ranks wait at the final barrier; cpu_baseline is an N = 1 figure by contract)
             del X, y
-            res['roofline'] = gather_roofline(device)
+            res['roofline'] = gather_roofline(device)[1]
         print(json.dumps(res), flush=True)
     if use_pg:
         dist.barrier()

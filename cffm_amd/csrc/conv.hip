@@ -4260,7 +4260,7 @@ bool cffm_wide_regather_ok(const cffm_shape_t* s) {
     if (check_shape(s) || !s->inner_conv || !s->outer_conv) return false;
     const Geo g = make_geo(s);
     return conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS && g.D / 2 <= 32 && 2 * g.F <= 64 &&
-           g.K == g.D && (g.K == 32 || g.K == 64) && g.F <= 32;
+           g.K == g.D && (g.K == 32 || g.K == 64) && g.F <= 32 && cffm_giw_lds_ok();
 }
 int cffm_outer_conv0_fwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st) {
     if (B <= 0 || !s->outer_conv) return 0;

@@ -116,9 +116,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // FS > 0: the field count as a compile-time constant (with K == D == 2*K2 this fixes the LDS image: every per-example offset of
 // the unit loop becomes an immediate of its ds_read_b64 instead of a v_add per read)
-template <int K2, int UPT, int ACTC, int FS>
+//
+// CIRC (round 4; the F = 32, K = D = 64 instance of BASELINE configs[3] / [4]): the pairs are dealt to the threads as a
+// CIRCULANT - half-wavefront (wave w, half h) owns row i = w + 16 h and the pairs {i, (i + d) & 31}, d = 1 .. 16 (d = 16 only
+// for h = 0: the 16 diameters) - instead of 16 consecutive pairs of the row-major list.  What that buys per unit:
+//   * the i-row piece is read from LDS once per example, not once per unit: 17 ds_read_b64 per 16 units instead of 32;
+//   * the j-row address is S(d) ^ V with S(d) = ((w + d) & 31) << 8 | buffer << 16 a SCALAR and V = h << 12 | 8 t one VGPR:
+//     one v_xor per (unit, FOUR examples) and no offset table in registers (16 VGPRs back);
+// NOT taken (measured, tools/probe_mfma_unit.hip, profiles/r04_probe_mfma_unit.txt): the 1x2 conv [x0, x1, 1] -> [z0, z1] (CFFM.py:327)
+// on the MFMA pipe.  v_mfma_f32_4x4x1_16b_f32 has exactly the right layout (16 blocks of D[m][n] = C[m][n] + A[m] * B[n], B[n] from
+// lane 4b+n = the lane's OWN x, D[.][n] back in that lane: confirmed on the box), but an MFMA holds the SIMD's vector issue port
+// for its whole 8 cycles: 8 VALU + 2 MFMA run at 29.4 ns per unit-wave per SIMD against 23.0 for the 10 VALU instructions (17.2
+// for the 8 alone) at this kernel's 4 waves per SIMD.  The pipe is idle, the issue port is not.
+template <int K2, int UPT, int ACTC, int FS, bool CIRC = false>
 __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInnerWideArgs a) {
     constexpr int E = GIW_E, T = GIW_T, K = 2 * K2, NG = T / K2;
+    static_assert(!CIRC || (K2 == 32 && UPT == 16 && FS == 32), "the circulant instance is F = 32, K = D = 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = FS > 0 ? FS : a.F, D = FS > 0 ? K : a.D, P = FS > 0 ? FS * (FS - 1) / 2 : a.P, act = ACTC >= 0 ? ACTC : a.act;
     const int K4 = K >> 2, D4 = D >> 2;
@@ -204,21 +217,34 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     if ((int)blockIdx.x < nphase) load_ids(blockIdx.x, 0);
 
     // ---- per-thread constants: its units' weights and LDS offsets ----------------------------------------------------
-    for (int i = tid; i < F; i += T) {
-        const int base = i * (2 * F - i - 1) / 2;
-        for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
+    if (!CIRC) {
+        for (int i = tid; i < F; i += T) {
+            const int base = i * (2 * F - i - 1) / 2;
+            for (int j = i + 1; j < F; ++j) lut[base + j - i - 1] = (uint32_t)i | ((uint32_t)j << 16);
+        }
+        for (int p = P + tid; p < NG * UPT; p += T) lut[p] = 0u;
     }
-    for (int p = P + tid; p < NG * UPT; p += T) lut[p] = 0u;
     const int g = tid / K2, t = tid - g * K2;
     f32x2 w[UPT];
-    uint32_t off[UPT];                                       // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
+    uint32_t off[CIRC ? 1 : UPT];                            // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
     const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the j-row addresses of the circulant are S(d) ^ V
+    const int half = lane >> 5, irow = wave + 16 * half;      // CIRC: this thread's row i
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
-        const int p = g * UPT + k;
-        w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
+        if (CIRC) {
+            const int d = k + 1, j = (irow + d) & 31;
+            const int lo = irow < j ? irow : j, hi = irow < j ? j : irow;
+            const int p = lo * (2 * 32 - lo - 1) / 2 + (hi - lo - 1);
+            w[k] = (d < 16 || half == 0) ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};   // the 16 diameters belong to the lower row
+        } else {
+            const int p = g * UPT + k;
+            w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
+        }
     }
     const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
+    const uint32_t Vx = ((uint32_t)half << 12) | (uint32_t)(8 * (lane & 31));     // CIRC: per-lane part of a j-row address
+    const uint32_t ai0 = ((uint32_t)irow << 8) | (uint32_t)(8 * (lane & 31));      // CIRC: the i-row piece inside an example image
     const float bd = a.bd[0];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first phase's ids (and the weights above) have landed
     __syncthreads();
@@ -226,14 +252,19 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
         load_rows(0, 0);
         if ((int)(blockIdx.x + gridDim.x) < nphase) load_ids(blockIdx.x + gridDim.x, 1);
     }
+    if (!CIRC) {
 #pragma unroll
-    for (int k = 0; k < UPT; ++k) {
-        const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
-        off[k] = (uint32_t)(((int)(ij & 0xffff) * K + 2 * t) * 4) | ((uint32_t)(((int)(ij >> 16) * K + 2 * t) * 4) << 16);
+        for (int k = 0; k < UPT; ++k) {
+            const uint32_t ij = lut[g * UPT + k];                             // padded pairs: (0, 0) with zero weights
+            off[k] = (uint32_t)(((int)(ij & 0xffff) * K + 2 * t) * 4) | ((uint32_t)(((int)(ij >> 16) * K + 2 * t) * 4) << 16);
+        }
     }
-    // the unit loop forms LDS addresses as (offset | buffer << 16): dynamic LDS starts at address 0 in a kernel without
-    // static __shared__ variables
+    // the unit loop forms LDS addresses as (offset | buffer << 16): dynamic LDS starts at address 0 in a kernel without static
+    // __shared__ variables.  The HOST checks that (giw_lds_base_ok: hipFuncGetAttributes().sharedSizeBytes == 0 for every instance,
+    // else cffm_wide_regather_ok() is false and the materialising path runs); the device-side trap is a debug build's.
+#ifdef CFFM_TILE_DBG
     if ((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+#endif
 
     int ph = blockIdx.x;
     if (ph < nphase) row_sums(0, ph, 0);
@@ -259,52 +290,111 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
         // below them (267 spilled registers under the 128-register budget of a 1024-thread workgroup).
         typedef const f32x2 __attribute__((address_space(3))) * lds2_t;
         static_assert(E == 4, "two half steps of two examples");
-        f32x2 eiA[2], ejA[2], eiB[2], ejB[2];
-        auto issue = [&](int k, int half, f32x2* ei, f32x2* ej) {
-            // two instructions per address pair: v_and_or_b32 and v_alignbit_b32 put the buffer bit on top of the 16-bit offsets
-            const uint32_t ai = (off[k] & 0xffffu) | ((uint32_t)par << 16);
-            const uint32_t aj = __builtin_amdgcn_alignbit((uint32_t)par, off[k], 16);
+        if constexpr (CIRC) {
+            // Steps of UB units x ONE example, examples innermost: step s = (batch s / E, example s % E).  The reads of step
+            // s + 1 (UB j-row pieces + the i-row piece, imm offset = example) are issued before step s is computed, into the
+            // other half of a register double buffer; the UB addresses of a batch are built once for its four examples.
+            constexpr int UB = 4, NB = UPT / UB, NS = NB * E;
+            f32x2 ejv[2][UB], eiv[2];
+            uint32_t ajv[2][UB];
+            const uint32_t pbit = (uint32_t)par << 16;
+            const uint32_t ai = ai0 | pbit;
+            auto mkaddr = [&](int kb, uint32_t* a4) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                ei[e] = *(lds2_t)(size_t)(ai + (2 * half + e) * slot_bytes);
-                ej[e] = *(lds2_t)(size_t)(aj + (2 * half + e) * slot_bytes);
+                for (int u = 0; u < UB; ++u) {
+                    const uint32_t S = ((uint32_t)((wave_s + kb * UB + u + 1) & 31) << 8) | pbit;    // scalar
+                    a4[u] = S ^ Vx;
+                }
+            };
+            auto issue = [&](int s_) {
+                const int kb = s_ / E, e = s_ % E;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) ejv[s_ & 1][u] = *(lds2_t)(size_t)(ajv[kb & 1][u] + e * slot_bytes);
+                eiv[s_ & 1] = *(lds2_t)(size_t)(ai + e * slot_bytes);
+            };
+            auto compute = [&](int s_) {
+                const int kb = s_ / E, e = s_ % E;
+                f32x2 x[UB], c[UB], zz[UB];
+                float mp[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) x[u] = eiv[s_ & 1] * ejv[s_ & 1][u];                      // :310
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { x[u].x = act_f(x[u].x, act); x[u].y = act_f(x[u].y, act); }   // :319
+#pragma unroll
+                for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].x, x[u].x}, w0, cb2);       // :327  cw[tap*2+ch]
+#pragma unroll
+                for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].y, x[u].y}, w1, zz[u]);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) mp[u] = fmaxf(x[u].x, x[u].y);                             // :331
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { c[u].x = act_pos(fmaxf(zz[u].x, 0.f), act); c[u].y = act_pos(fmaxf(zz[u].y, 0.f), act); }   // :478, :330
+#pragma unroll
+                for (int u = 0; u < UB; ++u) c[u] = c[u] + (f32x2){mp[u], mp[u]};                       // :332
+#pragma unroll
+                for (int u = 0; u < UB; ++u) acc[e] = __builtin_elementwise_fma(c[u], w[kb * UB + u], acc[e]);   // :339
+            };
+            mkaddr(0, ajv[0]);
+            issue(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                if (s_ + 1 < NS) {
+                    if ((s_ + 1) % E == 0) mkaddr((s_ + 1) / E, ajv[((s_ + 1) / E) & 1]);
+                    issue(s_ + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                compute(s_);
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        auto compute = [&](int k, int half, const f32x2* ei, const f32x2* ej) {
-            f32x2 x[2], z[2], c[2];
-            float mp[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) x[e] = ei[e] * ej[e];                                   // :310
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { x[e].x = act_f(x[e].x, act); x[e].y = act_f(x[e].y, act); }   // :319
-#pragma unroll
-            for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].x, x[e].x}, w0, cb2);   // :327  cw[tap*2+ch]
-#pragma unroll
-            for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].y, x[e].y}, w1, z[e]);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) mp[e] = fmaxf(x[e].x, x[e].y);                          // :331
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { c[e].x = act_pos(fmaxf(z[e].x, 0.f), act); c[e].y = act_pos(fmaxf(z[e].y, 0.f), act); }   // :478, :330
-#pragma unroll
-            for (int e = 0; e < 2; ++e) c[e] = c[e] + (f32x2){mp[e], mp[e]};                    // :332
-#pragma unroll
-            for (int e = 0; e < 2; ++e) acc[2 * half + e] = __builtin_elementwise_fma(c[e], w[k], acc[2 * half + e]);   // :339
-        };
-        issue(0, 0, eiA, ejA);
-        issue(0, 1, eiB, ejB);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < UPT; ++k) {
-            compute(k, 0, eiA, ejA);
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+        } else {
+            f32x2 eiA[2], ejA[2], eiB[2], ejB[2];
+            auto issue = [&](int k, int half, f32x2* ei, f32x2* ej) {
+                // two instructions per address pair: v_and_or_b32 and v_alignbit_b32 put the buffer bit on top of the 16-bit offsets
+                const uint32_t ai = (off[k] & 0xffffu) | ((uint32_t)par << 16);
+                const uint32_t aj = __builtin_amdgcn_alignbit((uint32_t)par, off[k], 16);
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ei[e] = *(lds2_t)(size_t)(ai + (2 * half + e) * slot_bytes);
+                    ej[e] = *(lds2_t)(size_t)(aj + (2 * half + e) * slot_bytes);
+                }
+            };
+            auto compute = [&](int k, int half, const f32x2* ei, const f32x2* ej) {
+                f32x2 x[2], z[2], c[2];
+                float mp[2];
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) x[e] = ei[e] * ej[e];                                   // :310
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) { x[e].x = act_f(x[e].x, act); x[e].y = act_f(x[e].y, act); }   // :319
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].x, x[e].x}, w0, cb2);   // :327  cw[tap*2+ch]
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) z[e] = __builtin_elementwise_fma((f32x2){x[e].y, x[e].y}, w1, z[e]);
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) mp[e] = fmaxf(x[e].x, x[e].y);                          // :331
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) { c[e].x = act_pos(fmaxf(z[e].x, 0.f), act); c[e].y = act_pos(fmaxf(z[e].y, 0.f), act); }   // :478, :330
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) c[e] = c[e] + (f32x2){mp[e], mp[e]};                    // :332
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) acc[2 * half + e] = __builtin_elementwise_fma(c[e], w[k], acc[2 * half + e]);   // :339
+            };
+            issue(0, 0, eiA, ejA);
+            issue(0, 1, eiB, ejB);
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < UPT) issue(k + 1, 0, eiA, ejA);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(k, 1, eiB, ejB);
-            asm volatile("" : "+v"(acc[2]), "+v"(acc[3]) : : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < UPT) issue(k + 1, 1, eiB, ejB);
-            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int k = 0; k < UPT; ++k) {
+                compute(k, 0, eiA, ejA);
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < UPT) issue(k + 1, 0, eiA, ejA);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(k, 1, eiB, ejB);
+                asm volatile("" : "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < UPT) issue(k + 1, 1, eiB, ejB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -342,23 +432,51 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     }
 }
 
-template <int K2, int UPT, int ACTC, int FS>
+template <int K2, int UPT, int ACTC, int FS, bool CIRC = false>
 static int launch_giw1(const GatherInnerWideArgs& a, int grid, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS, CIRC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS>), dim3(grid), dim3(GIW_T), lds, st, a);
+    hipLaunchKernelGGL((gather_inner_fwd_wide_kernel<K2, UPT, ACTC, FS, CIRC>), dim3(grid), dim3(GIW_T), lds, st, a);
     CFFM_CHECK_LAUNCH();
     return 0;
 }
 template <int K2, int UPT>
 static int launch_giw(const GatherInnerWideArgs& a, int grid, size_t lds, hipStream_t st) {
     if (K2 == 32 && UPT == 16 && a.F == 32 && a.D == 64) {          // BASELINE configs[3] / [4]: F32 K64 D64
-        if (a.act == CFFM_ACT_RELU) return launch_giw1<32, 16, CFFM_ACT_RELU, 32>(a, grid, lds, st);
-        return launch_giw1<32, 16, -1, 32>(a, grid, lds, st);
+        static const bool v3 = getenv("CFFM_GIW_V3") != nullptr;     // A/B runs: round 3's row-major pair assignment, 10 VALU per unit
+        if (v3) {
+            if (a.act == CFFM_ACT_RELU) return launch_giw1<32, 16, CFFM_ACT_RELU, 32>(a, grid, lds, st);
+            return launch_giw1<32, 16, -1, 32>(a, grid, lds, st);
+        }
+        if (a.act == CFFM_ACT_RELU) return launch_giw1<32, 16, CFFM_ACT_RELU, 32, true>(a, grid, lds, st);
+        return launch_giw1<32, 16, -1, 32, true>(a, grid, lds, st);
     }
     if (a.act == CFFM_ACT_RELU) return launch_giw1<K2, UPT, CFFM_ACT_RELU, 0>(a, grid, lds, st);
     return launch_giw1<K2, UPT, -1, 0>(a, grid, lds, st);
+}
+
+// Every instance forms LDS addresses as (offset | buffer << 16), i.e. assumes that its dynamic LDS starts at LDS address 0 - true
+// while the kernel has no static __shared__ variable.  Checked HERE, on the host, once: if a future edit or an instrumented build
+// gives any instance static LDS, cffm_wide_regather_ok() turns false and every composite takes the materialising path (cffm_gather
+// + the staged kernels) instead of aborting the GPU (the device-side trap is left to the CFFM_TILE_DBG build).
+bool cffm_giw_lds_ok() {
+    static int cached = -1;
+    if (cached >= 0) return cached != 0;
+    bool ok = true, asked = false;
+    auto chk = [&](const void* f) {
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, f) != hipSuccess) { (void)hipGetLastError(); return; }     // no device (layout queries on a CPU box)
+        asked = true;
+        if (at.sharedSizeBytes != 0) ok = false;
+    };
+#define GIW_CHK2(K2, UPT) chk((const void*)gather_inner_fwd_wide_kernel<K2, UPT, CFFM_ACT_RELU, 0>); chk((const void*)gather_inner_fwd_wide_kernel<K2, UPT, -1, 0>)
+    GIW_CHK2(32, 4); GIW_CHK2(32, 8); GIW_CHK2(32, 16); GIW_CHK2(16, 4); GIW_CHK2(16, 8); GIW_CHK2(16, 16);
+#undef GIW_CHK2
+    chk((const void*)gather_inner_fwd_wide_kernel<32, 16, CFFM_ACT_RELU, 32>); chk((const void*)gather_inner_fwd_wide_kernel<32, 16, -1, 32>);
+    chk((const void*)gather_inner_fwd_wide_kernel<32, 16, CFFM_ACT_RELU, 32, true>); chk((const void*)gather_inner_fwd_wide_kernel<32, 16, -1, 32, true>);
+    if (asked) cached = ok ? 1 : 0;
+    return ok;
 }
 
 int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,

@@ -69,6 +69,7 @@ int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_t
 
 // ---- wide shapes (Pp > 64): rows consumed where they are fetched, nothing materialised (RowSrc, common.hpp) ---------------
 bool cffm_wide_regather_ok(const cffm_shape_t* s);
+bool cffm_giw_lds_ok();     // the fused gather's LDS addressing assumption holds for every instance (inner.hip; checked on the host)
 // tf.nn.embedding_lookup x3 fused with the inner branch, the s0 pool and the first-order inputs: ids -> ws.inner_out,
 // ws.t1[:, 0:D] (s0), ws.fb, ws.sort_keys; Ei / Eo are NOT written
 int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,

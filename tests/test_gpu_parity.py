@@ -44,6 +44,10 @@ CASES = {
     'f16-k32-d32-b70-selu': dict(M=3000, F=16, K=32, D=32, act='selu', B=70),
     'f13-k64-d64-b9-prelu': dict(M=900, F=13, K=64, D=64, act='prelu', B=9),
     'f20-k32-d32-b3-relu': dict(M=900, F=20, K=32, D=32, act='relu', B=3),
+    # the F = 32, K = D = 64 instance of that kernel (circulant pair assignment, round 4) over several phases with a ragged last
+    # one: its generic-activation build (selu) and its relu build
+    'f32-k64-d64-b11-selu': dict(M=3000, F=32, K=64, D=64, act='selu', B=11),
+    'f32-k64-d64-b9-relu': dict(M=3000, F=32, K=64, D=64, act='relu', B=9),
     # more than 4,096 lookups per step: the rocPRIM radix sort + segment walk of the sparse update (the CLI's default
     # --batch_size 1024), with heavy duplication (ids drawn from 150 values per column)
     'frappe-b1024-dups': dict(M=5382, F=10, K=32, D=32, act='selu', B=1024, id_range=150),
@@ -129,7 +133,8 @@ def test_forward_stages(name):
     close(eng.predict(ids).cpu().numpy(), out_ref, 'predict')
 
 
-WIDE_NM = ['f32-d64-relu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu']
+WIDE_NM = ['f32-d64-relu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu', 'f32-k64-d64-b11-selu',
+           'f32-k64-d64-b9-relu']
 
 
 @pytest.mark.parametrize('name', WIDE_NM)
@@ -150,7 +155,8 @@ TRAIN_CASES = ['tiny-relu', 'd16-gelu', 'bookx-relu', 'frappe-selu', 'mltag-full
                'b257-relu', 'f20-d64-elu', 'f33-d32-relu', 'f16-d32-b130', 'f20-d32-b300-selu', 'frappe-b1024-dups',
                'bookx-b1024-dups', 'no-inner', 'no-outer', 'no-inner-no-outer', 'no-inner-nolinatt', 'no-outer-nolinatt',
                'fm-only-nolinatt', 'f10-d32-b100-elu', 'f7-d32-b64-gelu', 'f5-d32-b200-relu', 'f7-d32-b63-gelu',
-               'f11-d32-b256-relu', 'f6-d64-b256-elu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu']
+               'f11-d32-b256-relu', 'f6-d64-b256-elu', 'f16-k32-d32-b70-selu', 'f13-k64-d64-b9-prelu', 'f20-k32-d32-b3-relu',
+               'f32-k64-d64-b11-selu']
 
 
 @pytest.mark.parametrize('name,trained_like', [(n, t) for n in TRAIN_CASES for t in (True, False)] + [(n, True) for n in HEAVY])

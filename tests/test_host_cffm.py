@@ -351,3 +351,23 @@ def test_workspace_pool_frees_an_outgrown_buffer_with_its_last_graph():
     # an unpinned generation is not retired at all
     c.pool.get(20000)
     assert c.pool.retired == {} and c.ws_generation == 3
+
+
+def test_bench_leaves_with_one_line_when_fewer_gpus_than_ranks(monkeypatch, capsys):
+    """`bench.py --gpus N` on a node with fewer than N visible devices: every rank exits non-zero before any collective, rank 0
+    prints one line (the count is read in the launcher's children, never in the parent)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    import torch
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    for rank in (0, 1):
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2'])
+        for k, v in (('WORLD_SIZE', '2'), ('RANK', str(rank)), ('LOCAL_RANK', str(rank))):
+            monkeypatch.setenv(k, v)
+        monkeypatch.delenv('CFFM_BENCH_REHEARSAL', raising=False)
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert e.value.code == 3
+        err = capsys.readouterr().err
+        assert (err == 'bench.py: --gpus 2 needs 2 visible GPUs, this node shows 1\n') if rank == 0 else (err == '')

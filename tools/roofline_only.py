@@ -10,5 +10,5 @@ import bench  # noqa: E402
 
 if __name__ == '__main__':
     torch.cuda.set_device(0)
-    r = bench.gather_roofline(torch.device('cuda', 0))
+    r = bench.gather_roofline(torch.device("cuda", 0))[1]
     print(json.dumps(r))
