@@ -160,7 +160,7 @@ def gather_roofline(device, with_stress=False):
     achieved = bytes_per_launch / (ms_fused * 1e-3) / 1e9
     traffic, source = None, None      # HBM bytes per launch: rocprofv3 PMC passes of this command, committed under profiles/
     try:
-        source = 'profiles/r03_gather_pmc.json'
+        source = 'profiles/r04_gather_pmc.json'
         with open(os.path.join(ROOT, source)) as fh:
             traffic = int(json.load(fh)['gather_inner_fwd_wide_kernel']['hbm_bytes_per_launch'])
     except Exception:
@@ -172,9 +172,10 @@ def gather_roofline(device, with_stress=False):
     rate = lambda ms: round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)
     return stress, {'bound': 'hbm', 'kernel': 'gather_inner_fwd_wide_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
+            'hbm_busy': None if not traffic else round(traffic / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms_fused * 1e3, 2),
             'note': 'product-path kernel (cffm_train_step / cffm_predict at this shape): lookups fused with the inner branch, '
-                    'nothing materialised; VALU-bound, see DESIGN.md',
+                    'nothing materialised; VALU-bound, see DESIGN.md; hbm_busy = traffic (PMC bytes) / time / peak',
             'gather_packed_kernel': {'us_per_launch': round(ms_packed * 1e3, 2), 'achieved': rate(ms_packed)},
             'gather_rows_kernel': {'us_per_launch': round(ms_rows * 1e3, 2), 'achieved': rate(ms_rows)},
             'workload': 'synthetic libfm 32 fields dim 64 1M features batch 8192 uniform ids (tables 516 MB)'}

@@ -114,6 +114,39 @@ struct GatherInnerWideArgs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// x + |x| = 2 relu(x) in ONE v_add_f32 (abs source modifier).  As inline assembly: written in C the SLP vectoriser pairs two of them
+// into v_and_b32 x2 + v_pk_add_f32, three instructions for what two do.
+__device__ __forceinline__ float relu2(float x) {
+    float r;
+    asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// v_max_f32 as is: fmaxf() on the outputs of the assembly above gets two canonicalising v_max_f32 x, x in front (IEEE mode)
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// four wavefront sums as interleaved DPP chains (no hazard s_nops between the steps); every lane ends with the four totals
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0xB1, 0xf>(v[e], 0.f);     // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0x4E, 0xf>(v[e], 0.f);     // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0x141, 0xf>(v[e], 0.f);    // row_half_mirror
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0x140, 0xf>(v[e], 0.f);    // row_mirror
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0x142, 0xa>(v[e], 0.f);    // row_bcast:15
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += dpp_mov<0x143, 0xc>(v[e], 0.f);    // row_bcast:31 -> lane 63 holds the total
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[e]), 63));
+}
+
 // FS > 0: the field count as a compile-time constant (with K == D == 2*K2 this fixes the LDS image: every per-example offset of
 // the unit loop becomes an immediate of its ds_read_b64 instead of a v_add per read)
 //
@@ -144,7 +177,10 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     uint32_t* lut = reinterpret_cast<uint32_t*>(red + 2 * 16 * E);   // [NG * UPT] pair -> (i | j << 16)
     float* fbL = reinterpret_cast<float*>(lut + NG * UPT);           // [2][128] feature_bias of the slots of a phase (landing zone of the DMA)
     int* idsL = reinterpret_cast<int*>(fbL + 2 * 128);               // [2][128] raw ids of the slots of a phase
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x2* S0P = reinterpret_cast<f32x2*>(idsL + 2 * 128);           // CIRC: [2][4 quarters][E][64] (local s0 partial, column sum)
+    float* S0Q = reinterpret_cast<float*>(S0P + 2 * 4 * E * 64);     // CIRC: [2][4][E] row-sum totals of the quarters
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS bases (M0 of the row DMA) and the quarter / example of a wave cost no VALU
     const int nphase = (a.B + E - 1) / E;
 
     // ---- fetch role of this thread: piece q = tid of each of the E examples of a phase ------------------------------
@@ -152,8 +188,8 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     const bool is_in = tid < F * K4;
     const int fq = is_in ? tid / K4 : (tid - F * K4) / D4;                // field of the piece
     const int cq = is_in ? tid - fq * K4 : (tid - F * K4) - fq * D4;      // 16-byte piece inside the row
-    const float* tbl = is_in ? a.inner : a.outer;
-    const int rowlen4 = is_in ? K4 : D4;
+    const int rowlen4 = FS > 0 ? K4 : (is_in ? K4 : D4);                 // FS > 0: K == D, a compile-time shift
+    const f32x4* tbl = reinterpret_cast<const f32x4*>(is_in ? a.inner : a.outer) + cq;   // this thread's piece of row 0
     // The ids of a phase travel through LDS as well: thread tid < E*F owns slot (e, f) = (tid / F, tid % F) and fetches its id by a
     // 4-byte global_load_lds one phase before the rows that need it are requested; the fetch threads read the ids of their four
     // rows from there.  No id, no feature_bias value and no pointer to them is held in a register across the unit loop: with
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     const bool fo_on = tid < E * F;                                        // first-order role (:422) + id fetch: waves 0 .. E*F/64 - 1
     const int fo_e = fo_on ? tid / F : 0, fo_f = fo_on ? tid - fo_e * F : 0;
     const bool wave_has_outer = (wave + 1) * 64 > F * K4 && wave * 64 < npiece;      // some lane of this wave fetches an outer piece
-    auto clampid = [&](int id) { return id < 0 ? 0 : (id >= a.M ? a.M - 1 : id); };   // a bad id must not fault the GPU
+    auto clampid = [&](int id) { return (uint32_t)max(0, min(id, a.M - 1)); };          // v_med3_i32: a bad id must not fault the GPU
     auto load_ids = [&](int ph, int ib) {                                  // ids of phase ph -> idsL[ib]
         if (fo_on) {
             int b = ph * E + fo_e;
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 __builtin_amdgcn_global_load_lds(
-                    (const void __attribute__((address_space(1)))*)(reinterpret_cast<const f32x4*>(tbl) + (int64_t)clampid(idv[e]) * rowlen4 + cq),
+                    (const void __attribute__((address_space(1)))*)(tbl + (uint64_t)clampid(idv[e]) * (uint32_t)rowlen4),
                     (void __attribute__((address_space(3)))*)(rows + buf * buf_bytes + e * slot_bytes + wave * 1024), 16, 0, 0);
         }
         if (fo_on)
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     f32x2 w[UPT];
     uint32_t off[CIRC ? 1 : UPT];                            // LDS byte offsets of the unit's two rows inside an example image: i-row | j-row << 16
     const f32x2* wd2 = reinterpret_cast<const f32x2*>(a.wd);
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the j-row addresses of the circulant are S(d) ^ V
+    const int wave_s = wave;                                  // scalar: the j-row addresses of the circulant are S(d) ^ V
     const int half = lane >> 5, irow = wave + 16 * half;      // CIRC: this thread's row i
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
@@ -237,12 +273,14 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
             const int lo = irow < j ? irow : j, hi = irow < j ? j : irow;
             const int p = lo * (2 * 32 - lo - 1) / 2 + (hi - lo - 1);
             w[k] = (d < 16 || half == 0) ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};   // the 16 diameters belong to the lower row
+            if (ACTC == CFFM_ACT_RELU) w[k] = w[k] * 0.5f;                                  // the relu build works on 2 (c + mp), see compute()
         } else {
             const int p = g * UPT + k;
             w[k] = p < P ? wd2[(int64_t)p * K2 + t] : (f32x2){0.f, 0.f};      // flat index p*K + 2t + ch (:333)
         }
     }
     const f32x2 w0 = (f32x2){a.cw[0], a.cw[1]}, w1 = (f32x2){a.cw[2], a.cw[3]}, cb2 = (f32x2){a.cb[0], a.cb[1]};
+    const f32x2 w0h = w0 * 0.5f, w1h = w1 * 0.5f;                                 // CIRC relu build: taps of the doubled activations
     const uint32_t Vx = ((uint32_t)half << 12) | (uint32_t)(8 * (lane & 31));     // CIRC: per-lane part of a j-row address
     const uint32_t ai0 = ((uint32_t)irow << 8) | (uint32_t)(8 * (lane & 31));      // CIRC: the i-row piece inside an example image
     const float bd = a.bd[0];
@@ -318,20 +356,41 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
                 float mp[UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) x[u] = eiv[s_ & 1] * ejv[s_ & 1][u];                      // :310
+                if constexpr (ACTC == CFFM_ACT_RELU) {
+                    // relu twice over as x + |x| = 2 relu(x): v_add_f32 with the abs source modifier issues at 1.6 ns per wave
+                    // instruction per SIMD, v_max_f32 at 1.95 (profiles/r03_probe_valu.txt).  The factors of two are exact and are
+                    // taken back by the halved conv and dense weights (w0h, w1h, wh): (2a)(b/2) rounds exactly like ab, 2a + 2b
+                    // like 2(a + b) - the result is bit-identical to the max form.
 #pragma unroll
-                for (int u = 0; u < UB; ++u) { x[u].x = act_f(x[u].x, act); x[u].y = act_f(x[u].y, act); }   // :319
+                    for (int u = 0; u < UB; ++u) { x[u].x = relu2(x[u].x); x[u].y = relu2(x[u].y); }   // 2 relu(x) :319
 #pragma unroll
-                for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].x, x[u].x}, w0, cb2);       // :327  cw[tap*2+ch]
+                    for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].x, x[u].x}, w0h, cb2);      // :327 (exactly z)
 #pragma unroll
-                for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].y, x[u].y}, w1, zz[u]);
+                    for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].y, x[u].y}, w1h, zz[u]);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) mp[u] = fmaxf(x[u].x, x[u].y);                             // :331
+                    for (int u = 0; u < UB; ++u) mp[u] = max_raw(x[u].x, x[u].y);                       // 2 maxpool :331
 #pragma unroll
-                for (int u = 0; u < UB; ++u) { c[u].x = act_pos(fmaxf(zz[u].x, 0.f), act); c[u].y = act_pos(fmaxf(zz[u].y, 0.f), act); }   // :478, :330
+                    for (int u = 0; u < UB; ++u) { c[u].x = relu2(zz[u].x); c[u].y = relu2(zz[u].y); }   // 2 relu(z) :478, :330
 #pragma unroll
-                for (int u = 0; u < UB; ++u) c[u] = c[u] + (f32x2){mp[u], mp[u]};                       // :332
+                    for (int u = 0; u < UB; ++u) c[u] = c[u] + (f32x2){mp[u], mp[u]};                   // 2 (c + mp) :332
 #pragma unroll
-                for (int u = 0; u < UB; ++u) acc[e] = __builtin_elementwise_fma(c[u], w[kb * UB + u], acc[e]);   // :339
+                    for (int u = 0; u < UB; ++u) acc[e] = __builtin_elementwise_fma(c[u], w[kb * UB + u], acc[e]);   // w holds wd / 2 :339
+                } else {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { x[u].x = act_f(x[u].x, act); x[u].y = act_f(x[u].y, act); }   // :319
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].x, x[u].x}, w0, cb2);       // :327  cw[tap*2+ch]
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) zz[u] = __builtin_elementwise_fma((f32x2){x[u].y, x[u].y}, w1, zz[u]);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) mp[u] = fmaxf(x[u].x, x[u].y);                             // :331
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { c[u].x = act_pos(fmaxf(zz[u].x, 0.f), act); c[u].y = act_pos(fmaxf(zz[u].y, 0.f), act); }   // :478, :330
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) c[u] = c[u] + (f32x2){mp[u], mp[u]};                       // :332
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) acc[e] = __builtin_elementwise_fma(c[u], w[kb * UB + u], acc[e]);   // :339
+                }
             };
             mkaddr(0, ajv[0]);
             issue(0);
@@ -396,32 +455,75 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (CIRC) {
+            // the four wavefront sums as four INTERLEAVED DPP chains (one after the other every step waits out the DPP hazard in
+            // s_nops: 80 issue slots for the four, 34 interleaved), one 16-byte store of the four partials
+            float sv[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const float v = wave_sum(acc[e].x + acc[e].y);
-            if (lane == 0) red[(par * 16 + wave) * E + e] = v;
-        }
-        // ---- s0 pool (:381): s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]): wavefront e takes example e, lane = h
-        // (the same order of operations as head_fwd_body).  Waves 0..3 sit on four different SIMDs.
-        if (wave < E) {
-            const int e = wave, h = lane, b = ph * E + e;
-            const float* Eo = reinterpret_cast<const float*>(buf + e * slot_bytes) + F * K;
-            const float* rs = RS + (par * E + e) * 32;
-            const int hh = h < D ? h : 0;
-            float s = 0.f, R = 0.f;
-            int i = F - 2;
-            for (; i >= 7; i -= 8) {                                       // eight rows per step: their sixteen LDS reads are in flight together
-                float ev[8], rv[8];
+            for (int e = 0; e < E; ++e) sv[e] = acc[e].x + acc[e].y;
+            wave_sum4(sv);
+            if (lane == 0) *reinterpret_cast<f32x4*>(red + (par * 16 + wave) * E) = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+            // ---- s0 pool (:381) over ALL sixteen wavefronts: s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]).  Wave ->
+            // (example e = wave & 3, quarter q = wave >> 2) sweeps the rows i = 8q+7 .. 8q with R counted from the top of ITS quarter
+            // and keeps the column sum of its rows: s0 = sum_q (local_q + colsum_q * Rtop_q), Rtop_q = the row sums of the quarters
+            // above, put together behind the phase barrier.  The serial sweep on wavefronts 0 .. 3 alone was ~130 issue slots and
+            // four dependent LDS round trips at the END of their phase, run by one wave per SIMD while the other three waited.
+            {
+                const int e = wave_s & 3, q = wave_s >> 2, h = lane;
+                const float* Eo = reinterpret_cast<const float*>(buf + e * slot_bytes) + 32 * K + (8 * q) * 64 + h;
+                const float* rs = RS + (par * E + e) * 32 + 8 * q;
+                float ev[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { ev[u] = Eo[(i - u) * D + hh]; rv[u] = rs[i - u + 1]; }
+                for (int u = 0; u < 8; ++u) ev[u] = Eo[(7 - u) * 64];
+                const f32x4 rlo = *reinterpret_cast<const f32x4*>(rs), rhi = *reinterpret_cast<const f32x4*>(rs + 4);
+                const float rv[8] = {rhi.w, rhi.z, rhi.y, rhi.x, rlo.w, rlo.z, rlo.y, rlo.x};      // rows 8q+7 .. 8q
+                float R = 0.f, sl = 0.f, col = 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { R += rv[u]; s += ev[u] * R; }
+                for (int u = 0; u < 8; ++u) { sl += ev[u] * R; col += ev[u]; R += rv[u]; }
+                S0P[((par * 4 + q) * E + e) * 64 + h] = (f32x2){sl, col};
+                if (lane == 0) S0Q[(par * 4 + q) * E + e] = R;                  // the quarter's row-sum total
             }
-            for (; i >= 0; --i) { R += rs[i + 1]; s += Eo[i * D + hh] * R; }
-            if (h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
+        } else {
+    #pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float v = wave_sum(acc[e].x + acc[e].y);
+                if (lane == 0) red[(par * 16 + wave) * E + e] = v;
+            }
+            // ---- s0 pool (:381): s0[h] = sum_i Eo[i][h] * R_i, R_i = sum_{j>i} rowsum(Eo[j]): wavefront e takes example e, lane = h
+            // (the same order of operations as head_fwd_body).  Waves 0..3 sit on four different SIMDs.
+            if (wave < E) {
+                const int e = wave, h = lane, b = ph * E + e;
+                const float* Eo = reinterpret_cast<const float*>(buf + e * slot_bytes) + F * K;
+                const float* rs = RS + (par * E + e) * 32;
+                const int hh = h < D ? h : 0;
+                float s = 0.f, R = 0.f;
+                int i = F - 2;
+                for (; i >= 7; i -= 8) {                                       // eight rows per step: their sixteen LDS reads are in flight together
+                    float ev[8], rv[8];
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) { ev[u] = Eo[(i - u) * D + hh]; rv[u] = rs[i - u + 1]; }
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) { R += rv[u]; s += ev[u] * R; }
+                }
+                for (; i >= 0; --i) { R += rs[i + 1]; s += Eo[i * D + hh] * R; }
+                if (h < D && b < a.B) a.t1[(int64_t)b * a.t1w + h] = s;
+            }
         }
         if (more) row_sums(par ^ 1, nxt, par ^ 1);                                  // waits for the rows that were in flight
         __syncthreads();
+        if (CIRC && wave < E) {                                            // s0 of this phase: the four quarters, top rows first
+            const int b = ph * E + wave;
+            const f32x2* sp = S0P + (par * 4 * E + wave) * 64 + lane;
+            const float* qp = S0Q + par * 4 * E + wave;
+            float s0v = sp[3 * E * 64].x, Rt = qp[3 * E];
+#pragma unroll
+            for (int q = 2; q >= 0; --q) {
+                const f32x2 v = sp[q * E * 64];
+                s0v += v.x + v.y * Rt;
+                Rt += qp[q * E];
+            }
+            if (b < a.B) a.t1[(int64_t)b * a.t1w + lane] = s0v;
+        }
         if (tid < E) {                                                     // inner_out of this phase: wavefront partials in wave order
             const int b = ph * E + tid;
             float s = 0.f;
@@ -501,7 +603,7 @@ int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, 
     int grid = nphase < 256 ? nphase : 256;                    // one workgroup per CU, phases dealt round-robin
     int uptT = upt <= 4 ? 4 : (upt <= 8 ? 8 : 16);
     if (upt > 16) return CFFM_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)2 * 65536 + (size_t)(2 * GIW_E * 32 + 2 * 16 * GIW_E + NG * uptT + 4 * 128) * 4;
+    const size_t lds = (size_t)2 * 65536 + (size_t)(2 * GIW_E * 32 + 2 * 16 * GIW_E + NG * uptT + 4 * 128 + 2 * 4 * GIW_E * 64 * 2 + 2 * 4 * GIW_E) * 4;   // + S0P, S0Q (circulant instance)
     if (K2 == 32) {
         if (uptT == 4) return launch_giw<32, 4>(a, grid, lds, stream);
         if (uptT == 8) return launch_giw<32, 8>(a, grid, lds, stream);

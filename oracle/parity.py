@@ -4,6 +4,8 @@ TEST INFRASTRUCTURE, like everything under oracle/: only tests/, __graft_entry__
 import it; the product path (cffm_amd/) never does.  Holds close() - the three-tier element-wise bound - the WORST log, the
 slack helpers that account for fp32-vs-fp64 decisions at discontinuous gradients, and the two composite checks smoke() runs
 (check_backward_stages, check_gather_inner_fwd_wide), so that the entry file needs nothing from the tests package."""
+import os
+
 import numpy as np
 
 from . import cffm_oracle as orc
@@ -14,6 +16,7 @@ REL_FLOOR = 1e-2          # elements above REL_FLOOR * max|ref| must also be wit
                           # therefore binds exactly the <= 1 % of elements tier 1 lets through
 REL_TOL = 1e-3
 WORST = {}                # name -> worst (|err| / bound) seen, printed at the end of the session (see conftest)
+WORST_AT = {}             # name -> the test (PYTEST_CURRENT_TEST) that produced that worst ratio
 
 
 def close(got, ref, name, tol=TOL, ignore=None, extra=None):
@@ -51,7 +54,9 @@ def close(got, ref, name, tol=TOL, ignore=None, extra=None):
         bad &= ~ignore
     allowed = int(np.ceil(0.01 * ref.size)) if ref.size > 1 else 0
     ratio = float((err / bound).max())
-    WORST[name] = max(WORST.get(name, 0.0), ratio)
+    if ratio > WORST.get(name, -1.0):
+        WORST[name] = ratio
+        WORST_AT[name] = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
     rel_big = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
     assert not bad.any() and int(over1.sum()) <= allowed, \
         '%s: %d/%d beyond tol (%d allowed), %d beyond the hard bound, max err %.3e (rms %.3e, max %.3e), worst err/bound ' \

@@ -41,5 +41,8 @@ def pytest_sessionfinish(session, exitstatus):
             os.makedirs(out, exist_ok=True)
             with open(os.path.join(out, 'parity_worst.json'), 'w') as fh:
                 json.dump(dict(sorted(worst.items(), key=lambda kv: -kv[1])), fh, indent=1)
+            where = getattr(sys.modules.get('oracle.parity'), 'WORST_AT', {})
+            with open(os.path.join(out, 'parity_worst_at.json'), 'w') as fh:
+                json.dump({k: where.get(k, '') for k, _ in sorted(worst.items(), key=lambda kv: -kv[1])}, fh, indent=1)
     except Exception:
         pass
