@@ -393,7 +393,7 @@ def main():
             eng = HipEngine(lcfg, params='device', seed=2021, table_seed=2021 + rank, device=str(device))
         else:
             eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=2021), rank, world), device=str(device))
-        sh = ShardedStep(eng)
+        sh = ShardedStep(eng, M_global=cfg.M)
         Xb, yb = [X[i] for i in range(n_pool)], [y[i] for i in range(n_pool)]
         # the routing plan of the next batch is issued one step ahead (its per-owner counts are on the host before needed)
         step = lambda i: sh.train_step(Xb[i % n_pool], yb[i % n_pool], next_ids=Xb[(i + 1) % n_pool])

@@ -73,6 +73,8 @@ PYBIND11_MODULE(_cffm_pybind, m) {
     CFFM_BIND(cffm_gather_packed);
     CFFM_BIND(cffm_stage_packed);
     CFFM_BIND(cffm_pack_rows_dedup);
+    CFFM_BIND(cffm_shard_plan_scratch_bytes);
+    CFFM_BIND(cffm_shard_plan);
     CFFM_BIND(cffm_eval_scratch_bytes);
     CFFM_BIND(cffm_eval_sums);
     CFFM_BIND(cffm_probe_copy);

@@ -282,12 +282,21 @@ class ShardedStep(object):
     never waits.  ``compute`` owns a LOCAL engine (cfg.M = local_rows_count): HipEngine in the product, the oracle in the
     CPU tests."""
 
-    def __init__(self, compute, group=None, dedup=True, sync=True):
+    def __init__(self, compute, group=None, dedup=True, sync=True, M_global=None):
         self.c = compute
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.dedup = dedup
+        # rows of the GLOBAL tables (the compute engine only knows its own share): bounds the local-row bits of the device-side
+        # plan.  Default: the largest vocabulary whose shares are what the ranks own (local_rows_count is within 1 across ranks).
+        if M_global is None and hasattr(compute, 'cfg'):
+            on_host = dist.get_backend(group) == 'gloo'
+            m_loc = torch.tensor([int(compute.cfg.M)], dtype=torch.int64, device='cpu' if on_host else getattr(compute, 'device', 'cpu'))
+            if self.world > 1:
+                dist.all_reduce(m_loc, op=dist.ReduceOp.MAX, group=group)
+            M_global = int(m_loc.item()) * self.world
+        self.M_global = M_global
         self._ahead = None
         self.plans_built = self.plans_reused = 0      # how often a prefetched plan was consumed (tests, bench)
         if sync and self.world > 1:
@@ -299,7 +308,9 @@ class ShardedStep(object):
         dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group)
         return recv
 
-    def plan(self, ids):
+    def plan_torch(self, ids):
+        """The plan as torch operations on any device: the specification of cffm_shard_plan (tests compare the two), and what the
+        CPU tests (gloo, the oracle as compute) run."""
         G = self.world
         B, F = ids.shape
         n = B * F
@@ -321,15 +332,25 @@ class ShardedStep(object):
             counts = torch.bincount(owner, minlength=G)
         pos = torch.empty(n, dtype=torch.int64, device=dev)
         pos[order] = uniq                                             # slot -> record of the answer
+        return (local.to(torch.int32).reshape(B, F).contiguous(), order.to(torch.int32), uniq.to(torch.int32), pos.to(torch.int32),
+                send_rows.to(torch.int32), counts)
+
+    def plan(self, ids):
+        G = self.world
+        B, F = ids.shape
+        dev = ids.device
+        if self.dedup and hasattr(self.c, 'shard_plan') and self.M_global is not None:
+            # the product path: five small launches in the library instead of ~15 torch operations with int64 temporaries
+            local_ids, order, uniq, pos, send_rows, counts = self.c.shard_plan(ids, G, self.M_global)
+        else:
+            local_ids, order, uniq, pos, send_rows, counts = self.plan_torch(ids)
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts, group=self.group)
         both = torch.stack([counts, recv_counts])
         p = _Plan()
         self.plans_built += 1
         p.ids, p.token, p.B, p.F = ids, batch_token(ids), B, F
-        p.local_ids = local.to(torch.int32).reshape(B, F).contiguous()
-        p.order, p.uniq, p.pos = order.to(torch.int32), uniq.to(torch.int32), pos.to(torch.int32)
-        p.send_rows = send_rows.to(torch.int32)
+        p.local_ids, p.order, p.uniq, p.pos, p.send_rows = local_ids, order, uniq, pos, send_rows
         p._sc = p._rc = None
         if dev.type == 'cuda':
             p.counts_host = torch.empty((2, G), dtype=torch.int64, pin_memory=True)

@@ -383,6 +383,28 @@ class HipEngine(object):
         buf, _ = self.workspace(B)
         hip.check(self.lib.cffm_gather_inner_fwd(self._s, self._t, _ptr(self.theta), _ptr(ids), B, _ptr(buf), self._stream()))
 
+    def shard_plan(self, ids, world, M_global):
+        """Routing plan of a [B,F] id batch through tables of M_global rows sharded r -> (r % world, r // world), entirely on the
+        device (cffm_shard_plan: pack, one radix sort, head flags, scan, scatter - no int64 temporaries, no torch.sort).
+        Returns int32 tensors (local_ids [B,F], order, uniq, pos, send_rows [B*F]) and counts int64 [world]."""
+        ids = self._ids(ids)
+        n = int(ids.numel())
+        key = ('plan', n)
+        scratch = self._ws.get(key)
+        if scratch is None:
+            nbytes = int(self.lib.cffm_shard_plan_scratch_bytes(n))
+            if nbytes < 0:
+                raise RuntimeError('cffm_shard_plan_scratch_bytes failed')
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = scratch
+        dev = self.device
+        local_ids = torch.empty(ids.shape, dtype=torch.int32, device=dev)
+        order, uniq, pos, send_rows = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4))
+        counts = torch.empty(int(world), dtype=torch.int64, device=dev)
+        hip.check(self.lib.cffm_shard_plan(_ptr(ids), n, int(world), int(M_global), _ptr(scratch), _ptr(local_ids), _ptr(order),
+                                           _ptr(uniq), _ptr(pos), _ptr(send_rows), _ptr(counts), self._stream()))
+        return local_ids, order, uniq, pos, send_rows, counts
+
     def gather_packed(self, local_rows):
         """Owner side of a row-sharded lookup: int32 [m] local rows -> [m, K+D+4] packed records
         (inner | outer | bias, 0, 0, 0), ONE kernel (cffm_gather_packed)."""

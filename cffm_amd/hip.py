@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CFFM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcffm_hip.so')   # CFFM_HIP_LIB: another build of the library (A/B timing of kernel variants)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LAYERS = 8
 NSLAB = 64
 HEAD_UNITS = 32
@@ -95,6 +95,8 @@ PROTOTYPES = {
     'cffm_gather_packed': (C.c_int, [_SH, _TB, _P, C.c_int64, _P, _P]),
     'cffm_stage_packed': (C.c_int, [_SH, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     'cffm_pack_rows_dedup': (C.c_int, [_SH, _P, _P, _P, C.c_int32, _P, _P, _P]),
+    'cffm_shard_plan_scratch_bytes': (C.c_int64, [C.c_int64]),
+    'cffm_shard_plan': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'cffm_eval_scratch_bytes': (C.c_int64, []),
     'cffm_eval_sums': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CFFM_ABI_VERSION 8
+#define CFFM_ABI_VERSION 9
 #define CFFM_MAX_LAYERS 8          /* live conv layers = log2(D) - 1 <= 8  (D <= 512)          */
 #define CFFM_MAX_FIELDS 64         /* linear-attention softmax runs inside one 64-lane wavefront */
 #define CFFM_HEAD_UNITS 32         /* tf.layers.dense(units=32), CFFM.py:409                    */
@@ -260,6 +260,17 @@ int cffm_stage_packed(const cffm_shape_t *s, const float *packed, const int32_t 
  * dEo | dfb), the row format cffm_dp_apply takes */
 int cffm_pack_rows_dedup(const cffm_shape_t *s, const int32_t *local_ids, const int32_t *order, const int32_t *uniq, int32_t B,
                          void *ws, float *out, void *stream);
+
+/* routing plan of one [B,F] batch (n = B*F slots) through tables of M global rows sharded r -> (rank r % world, local row r / world);
+ * a function of the ids alone, so ShardedStep issues it one step ahead.  All outputs int32 [n] except counts int64 [world]:
+ *   local_ids  owner's local row of every slot                       order  slot at sorted position q ((owner, local row) order,
+ *   uniq       index of the distinct (owner, local row) pair at q           stable: slots ascend inside a run of equal ids)
+ *   pos        slot -> index of its distinct pair                    send_rows  local row of distinct pair u (first #distinct used)
+ *   counts     distinct pairs per owner = the split sizes of the three all-to-alls (summed: #distinct)
+ * = what cffm_pack_rows_dedup / cffm_stage_packed take.  scratch: cffm_shard_plan_scratch_bytes(n) bytes.  ids must lie in [0, M). */
+int64_t cffm_shard_plan_scratch_bytes(int64_t n);
+int cffm_shard_plan(const int32_t *ids, int64_t n, int32_t world, int64_t M, void *scratch, int32_t *local_ids, int32_t *order,
+                    int32_t *uniq, int32_t *pos, int32_t *send_rows, int64_t *counts, void *stream);
 
 /* ---- evaluate() (CFFM.py:583-615) without a device-to-host copy of the predictions ------------------------------- */
 /* clip + metric sums of CFFM.py:607-614 over n rows: p = min(max(pred, lo), hi) with lo/hi = min/max of the split's labels;

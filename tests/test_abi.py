@@ -28,14 +28,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cffm_abi_version() == hip.ABI_VERSION == 8
+    assert lib.cffm_abi_version() == hip.ABI_VERSION == 9
     assert b'bad shape' in lib.cffm_error_string(10001)
     # the pybind11 layer (north_star's binding) exposes the same entry points and is what the engine calls through
     fast = hip.fast()
     assert hip.binding_name() == 'pybind11', 'cffm_amd/lib/_cffm_pybind*.so is not built (make)'
     for name in declared:
         assert callable(getattr(fast, name)), name
-    assert fast.cffm_abi_version() == 8 and 'bad shape' in fast.cffm_error_string(10001)
+    assert fast.cffm_abi_version() == 9 and 'bad shape' in fast.cffm_error_string(10001)
     sh = hip.make_shape(CFFMConfig(M=10, F=3, K=8, D=8))
     assert fast.cffm_packed_row_floats(C.addressof(sh)) == lib.cffm_packed_row_floats(C.byref(sh)) == 20
     tl_a, tl_b = hip.ThetaLayout(), hip.ThetaLayout()

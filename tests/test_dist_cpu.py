@@ -499,3 +499,27 @@ def test_cffm_class_trains_data_parallel_under_a_process_group(tmp_path):
             np.testing.assert_allclose(two[rank][1][k], v, rtol=1e-8, atol=1e-11, err_msg='rank %d %s' % (rank, k))
     for k in two[0][1]:
         np.testing.assert_array_equal(two[0][1][k], two[1][1][k], err_msg=k)
+
+
+def test_plan_torch_against_a_plain_numpy_reading():
+    """ShardedStep.plan_torch is the specification the device kernel (cffm_shard_plan) is tested against on the GPU: pin it here
+    against a loop-level numpy reading of the same definition."""
+    from cffm_amd.dist import ShardedStep
+    rng = np.random.default_rng(5)
+    B, F, M, G = 37, 5, 97, 3
+    X = rng.integers(0, 30, size=(B, F)).astype(np.int32) * 3 + 1
+    X[X >= M] = M - 1
+    st = ShardedStep.__new__(ShardedStep)
+    st.world, st.dedup = G, True
+    local_ids, order, uniq, pos, send_rows, counts = [t.numpy() for t in st.plan_torch(torch.from_numpy(X))]
+    flat = X.reshape(-1).astype(np.int64)
+    pairs = [(int(v % G), int(v // G)) for v in flat]
+    want_order = sorted(range(len(flat)), key=lambda i: (pairs[i], i))          # stable: slots ascend inside a run
+    distinct = sorted(set(pairs))
+    index = {p: u for u, p in enumerate(distinct)}
+    assert local_ids.reshape(-1).tolist() == [p[1] for p in pairs]
+    assert order.tolist() == want_order
+    assert uniq.tolist() == [index[pairs[i]] for i in want_order]
+    assert pos.tolist() == [index[p] for p in pairs]
+    assert send_rows[:len(distinct)].tolist() == [p[1] for p in distinct]
+    assert counts.tolist() == [sum(1 for p in distinct if p[0] == o) for o in range(G)]

@@ -168,3 +168,38 @@ def test_cffm_class_trains_data_parallel_on_the_gpu(tmp_path):
         np.testing.assert_array_equal(np.asarray(two[0][1][k]), np.asarray(two[1][1][k]), err_msg=k)
     for a, b in zip(one[0], two[0][0]):                      # and the single-process run's, up to fp32 summation order over two
         np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=2e-2, atol=2e-3)   # free-running epochs (header)
+
+
+@pytest.mark.parametrize('n_rows,F,M,world,id_range', [(8192, 32, 10_000_000, 8, None), (300, 10, 5382, 2, 40), (1, 3, 17, 4, None),
+                                                      (4096, 6, 226336, 3, 500), (70, 16, 3000, 1, None)])
+def test_device_shard_plan_equals_the_torch_plan(n_rows, F, M, world, id_range):
+    """cffm_shard_plan (pack -> one radix sort -> head flags -> scan -> scatter, csrc/plan.hip) against ShardedStep.plan_torch, the ~15
+    torch operations it replaces and its specification: every output identical - local rows, the stable (owner, local row) order
+    with slots ascending inside a run, the distinct-pair index of every sorted position and of every slot, the request list and the
+    per-owner counts - at cfg5's per-GPU share (8192 x 32 lookups, 10 M features, 8 owners), with heavy duplication, with a single
+    row, with a world size that is not a power of two and at world size 1."""
+    from cffm_amd.dist import ShardedStep
+    from cffm_amd.engine import HipEngine
+    rng = np.random.default_rng(n_rows + world)
+    X = rng.integers(0, id_range or M, size=(n_rows, F)).astype(np.int32)
+    if id_range:
+        X = (X.astype(np.int64) * (M // id_range)).astype(np.int32)        # few distinct values, spread over the owners
+    X[-1, 0] = M - 1                                                        # the last row of the vocabulary
+    ids = torch.from_numpy(X).cuda()
+    eng = HipEngine(CFFMConfig(M=64, F=F, K=8, D=8), device='cuda:0')       # the plan depends on the ids only
+    st = ShardedStep.__new__(ShardedStep)
+    st.world, st.dedup = world, True
+    want = st.plan_torch(ids)
+    got = eng.shard_plan(ids, world, M)
+    torch.cuda.synchronize()
+    n_distinct = int(want[5].sum())
+    names = ('local_ids', 'order', 'uniq', 'pos', 'send_rows', 'counts')
+    for name, a, b in zip(names, got, want):
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        if name == 'send_rows':                                             # capacity n, the first #distinct entries are defined
+            a, b = a[:n_distinct], b[:n_distinct]
+        assert torch.equal(a, b), name
+    assert n_distinct == int(got[2].max()) + 1 and int(got[5].sum()) == n_distinct
+    # and twice in a row on the same scratch (the counts are re-zeroed by the call itself)
+    again = eng.shard_plan(ids, world, M)
+    assert torch.equal(again[5], want[5]) and torch.equal(again[3], want[3])
