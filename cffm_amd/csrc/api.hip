@@ -118,8 +118,10 @@ static bool wide_rows(const cffm_shape_t* s, const cffm_tables_t* tab, const int
     return tab && ids && cffm_wide_regather_ok(s);
 }
 
+// rstride / rrows > 0 (wide shapes only): tab is a view into packed records of rstride floats, rrows of them (see RowSrc)
 static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids,
-                        const float* y, int32_t B, void* ws, bool fused_step, hipStream_t stream, bool no_materialise = false) {
+                        const float* y, int32_t B, void* ws, bool fused_step, hipStream_t stream, bool no_materialise = false,
+                        int rstride = 0, int rrows = 0) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -128,8 +130,8 @@ static int forward_impl(const cffm_shape_t* s, const cffm_tables_t* tab, const f
     char* w = (char*)ws;
     const Geo g = make_geo(s);
     if (no_materialise && wide_rows(s, tab, ids)) {
-        if ((rc = cffm_gather_inner_fwd_wide(s, tab, theta, ids, B, ws, stream))) return rc;
-        const RowSrc ro = {tab->outer_emb, ids, s->M};
+        if ((rc = cffm_gather_inner_fwd_wide(s, tab, theta, ids, B, ws, stream, rstride, rrows))) return rc;
+        const RowSrc ro = {tab->outer_emb, ids, rrows > 0 ? rrows : s->M, rstride};
         if ((rc = cffm_outer_conv0_fwd_rows(s, theta, ws, B, &ro, stream))) return rc;
         for (int l = 1; l < g.live; ++l)
             if ((rc = cffm_conv_fwd(s, theta, ws, B, l, stream))) return rc;
@@ -179,7 +181,7 @@ extern "C" int cffm_predict(const cffm_shape_t* s, const cffm_tables_t* tab, con
 static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, const float* y, int32_t B,
                          int64_t B_global, void* ws, float* grad, bool fused, float* loss_out, hipStream_t stream,
                          bool unscaled = false, bool skip_reduce = false, const int32_t* rank_ids = nullptr,
-                         const cffm_tables_t* rtab = nullptr, const int32_t* rids = nullptr) {
+                         const cffm_tables_t* rtab = nullptr, const int32_t* rids = nullptr, int rstride = 0, int rrows = 0) {
     int rc = check_shape(s);
     if (rc) return rc;
     if (B <= 0) return 0;
@@ -219,7 +221,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
                 if (rc) return rc;
             }
             if (wide) {
-                const RowSrc ro = {rtab->outer_emb, rids, s->M};
+                const RowSrc ro = {rtab->outer_emb, rids, rrows > 0 ? rrows : s->M, rstride};
                 rc = cffm_outer_conv0_bwd_rows(s, theta, ws, B, &ro, stream);
             } else {
                 rc = cffm_outer_conv0_bwd(s, theta, ws, B, stream);
@@ -229,7 +231,7 @@ static int backward_impl(const cffm_shape_t* s, float* theta, float* theta_acc, 
     }
     if (!inner_done) {
         if (wide) {
-            const RowSrc ri = {rtab->inner_emb, rids, s->M};
+            const RowSrc ri = {rtab->inner_emb, rids, rrows > 0 ? rrows : s->M, rstride};
             rc = cffm_inner_bwd_rows(s, theta, ws, B, &ri, stream);
         } else {
             rc = cffm_inner_bwd(s, theta, ws, B, stream);
@@ -266,6 +268,37 @@ extern "C" int cffm_backward_unscaled(const cffm_shape_t* s, const float* theta,
     return cffm_pack_rows(s, ids, B, s->inner_conv ? (const float*)(w + wl.dEi) : nullptr,
                           s->outer_conv ? (const float*)(w + wl.dEo) : nullptr, (const float*)(w + wl.dfb),
                           (const float*)(w + wl.scalars), grad + tl.n, rows, (hipStream_t)stream);
+}
+
+// ---- row-sharded step without staging (cffm_amd/dist.py ShardedStep): the packed records a rank received ARE the tables ------
+static bool packed_view(const cffm_shape_t* s, const float* packed, int64_t n_records, cffm_tables_t* view) {
+    if (check_shape(s) || !packed || n_records <= 0 || n_records >= (1ll << 31) || !cffm_wide_regather_ok(s)) return false;
+    view->inner_emb = const_cast<float*>(packed);
+    view->outer_emb = const_cast<float*>(packed) + s->K;
+    view->feat_bias = const_cast<float*>(packed) + s->K + s->D;
+    return true;
+}
+extern "C" int cffm_forward_packed(const cffm_shape_t* s, const float* theta, const float* packed, const int32_t* pos,
+                                   int64_t n_records, const float* y, int32_t B, void* ws, void* stream) {
+    cffm_tables_t view;
+    if (B <= 0) return check_shape(s);
+    if (!pos || !packed_view(s, packed, n_records, &view)) return CFFM_ERR_UNSUPPORTED;
+    return forward_impl(s, &view, theta, pos, y, B, ws, false, (hipStream_t)stream, true, s->K + s->D + 4, (int)n_records);
+}
+extern "C" int cffm_backward_unscaled_packed(const cffm_shape_t* s, const float* theta, const float* packed, const int32_t* pos,
+                                             int64_t n_records, const float* y, int32_t B, int64_t B_global, void* ws, float* grad,
+                                             void* stream) {
+    if (s && (s->loss == CFFM_LOSS_HYBRID || s->loss == CFFM_LOSS_SQUARE_L2)) return CFFM_ERR_UNSUPPORTED;   // single-process only
+    cffm_tables_t view;
+    if (B <= 0) return check_shape(s);
+    if (!pos || !packed_view(s, packed, n_records, &view)) return CFFM_ERR_UNSUPPORTED;
+    int rc = backward_impl(s, const_cast<float*>(theta), nullptr, y, B, B_global, ws, grad, false, nullptr, (hipStream_t)stream, true,
+                           false, nullptr, &view, pos, s->K + s->D + 4, (int)n_records);
+    if (rc) return rc;
+    cffm_ws_layout_t wl; cffm_theta_layout_t tl;
+    cffm_ws_layout(s, B, &wl); cffm_theta_layout(s, &tl);
+    hipError_t e = hipMemcpyAsync(grad + tl.n, (char*)ws + wl.scalars, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // the key placement can leave the forward launch when the fused top of the backward runs (and is not the L2 loss path)

@@ -134,16 +134,18 @@ struct RowSrc {
     const float* base;
     const int32_t* idx;
     int M;
+    int stride = 0;      // floats between consecutive rows of base; 0 = the row length.  The row-sharded step reads its rows out of the
+                         // packed records it received ([n_records][K+D+4]: base = records (+ K for the outer row), idx = slot -> record)
 };
-__device__ __forceinline__ const float* row_ptr(const float* base, const int32_t* idx, int M, int64_t slot, int dim) {
+__device__ __forceinline__ const float* row_ptr(const float* base, const int32_t* idx, int M, int64_t slot, int dim, int stride = 0) {
     if (idx == nullptr) return base + slot * dim;
     int id = idx[slot];
     id = id < 0 ? 0 : (id >= M ? M - 1 : id);               // clamp: a bad id must not fault the GPU
-    return base + (int64_t)id * dim;
+    return base + (int64_t)id * (stride > 0 ? stride : dim);
 }
 // [F][D] rows of example b -> LDS tile Es[f * Dp + d] (the staging loop of the tiled layer-0 kernels)
 __device__ __forceinline__ void stage_example_rows(float* Es, const float* base, const int32_t* idx, int M, int b, int F, int D,
-                                                   int Dp, int tid, int nth) {
+                                                   int Dp, int tid, int nth, int stride = 0) {
     const float invD = 1.f / (float)D;
     if (idx == nullptr) {
         const float* e = base + (int64_t)b * F * D;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void stage_example_rows(float* Es, const float* base,
     } else {
         for (int i = tid; i < F * D; i += nth) {
             const int f = (int)(((float)i + 0.5f) * invD), d = i - f * D;
-            Es[f * Dp + d] = row_ptr(base, idx, M, (int64_t)b * F + f, D)[d];
+            Es[f * Dp + d] = row_ptr(base, idx, M, (int64_t)b * F + f, D, stride)[d];
         }
     }
 }

@@ -189,6 +189,7 @@ struct ConvArgs {
     int dbg;             // debug build only (make TILE_DBG=1): phase-skipping bits for tools/dbg_tile.py, 0 otherwise
     const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = `in` is the outer TABLE [M][D] and row (b, f) is idx[b*F+f] (RowSrc)
     int idxM = 0;
+    int idxStride = 0;              // floats between rows of the table (0 = D): see RowSrc
     float* pool = nullptr;          // wide shapes: partial sum pools of act(out), [B][So][pool_np] (pool_partials(), common.hpp)
     int pool_np = 0;
     uint16_t* relu = nullptr;       // wide shapes (tiled layer-0 forward, conv_fwd_kernel): bit mask of out > 0, [B*So*So][Pp/16] 16-bit words (ws.relu0)
@@ -346,6 +347,7 @@ struct DgradArgs {
     int nblk;            // dgrad_kernel, L0 = false: column blocks of a row tile (1-D grid, see xcd_tile)
     const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = Cprev is the outer TABLE [M][D], row (b, f) = idx[b*F+f] (RowSrc)
     int idxM = 0;
+    int idxStride = 0;              // floats between rows of the table (0 = D): see RowSrc
     const uint16_t* relu = nullptr; // dgrad_kernel, L0 = false: bit mask of C_{l-1} > 0 ([rows of C_{l-1}][Pp/16] words) read INSTEAD of C_{l-1}
 };
 
@@ -590,6 +592,7 @@ struct WgradArgs {
     int nslab, nxy;      // wgrad_kernel: gradient slabs and output tiles per slab (1-D grid, see xcd_tile)
     const int32_t* idx = nullptr;   // tiled layer 0 only: non-NULL = `in` is the outer TABLE [M][D], row (b, f) = idx[b*F+f] (RowSrc)
     int idxM = 0;
+    int idxStride = 0;              // floats between rows of the table (0 = D): see RowSrc
 };
 
 // Generic form (64 x 16*NT output tile per workgroup): the direct layer 0 (GEN, F >= 33) and column-tile counts other than
@@ -2553,7 +2556,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_fwd_kernel(ConvArg
 #else
     constexpr int dbg = 0;
 #endif
-    stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
+    stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH, a.idxStride);
     lds_barrier();
     // ---- step 1 -----------------------------------------------------------------------------------------------------
     // The kernel is instruction-issue-bound (with every load, MFMA and store switched off it still ran 11.6 of its 29.2 ms
@@ -2693,7 +2696,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_wgrad_kernel(Wgrad
     float bsum = 0.f;                                          // bias partial of channel q0 + (tid & 15), rows tid >> 4 (g == 0 only)
     for (int b = slab; b < a.B; b += nslab) {
         __syncthreads();                                       // previous example fully consumed
-        stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
+        stage_example_rows(Es, a.in, a.idx, a.idxM, b, F, D, Dp, tid, NTH, a.idxStride);
         for (int xt = 0; xt < RT; ++xt) {
             const int x0 = xt * 16;
             if (xt > 0) __syncthreads();                       // dCt / dTg of the previous column tile consumed
@@ -2863,7 +2866,7 @@ __global__ __launch_bounds__(1024) void conv0_fact_tile_wgrad_all_kernel(WgradAr
     };
     auto fetch_rows = [&](int b, int buf) {
         for (int f = wave; f < F; f += 16) {
-            const float* row = row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D);
+            const float* row = row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D, a.idxStride);
             if (lane < D)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + lane),
                                                  (void __attribute__((address_space(3)))*)(Es0 + buf * EsN + f * Dp), 4, 0, 0);
@@ -3035,7 +3038,7 @@ __global__ __launch_bounds__(64 * NW) void conv0_fact_tile_dgrad_kernel(DgradArg
     float* rs = dTg + 4096;                                     // [F] row sums, [F] dots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x;
-    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
+    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH, a.idxStride);
     f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt)
@@ -3292,7 +3295,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv0_fact_tile_dgrad2_kernel(Dgra
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x;
     const unsigned ulane = lane;
-    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH);
+    stage_example_rows(Es, a.Cprev, a.idx, a.idxM, b, F, D, Dp, tid, NTH, a.idxStride);
     for (int e = tid; e < (Fp + 1 - F) * Dp; e += NTH) Es[F * Dp + e] = 0.f;
     f32x4 accE[2][4];                                          // [column tile][row tile of (dw,j)]
 #pragma unroll
@@ -3624,7 +3627,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv0_fact_tile_fwd2_kernel(ConvAr
         const float invD = 1.f / (float)D;
         for (int e = tid; e < F * D; e += NTH) {
             const int f = (int)(((float)e + 0.5f) * invD), d = e - f * D;
-            const float v = a.idx == nullptr ? a.in[((int64_t)b * F + f) * D + d] : row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D)[d];
+            const float v = a.idx == nullptr ? a.in[((int64_t)b * F + f) * D + d] : row_ptr(a.in, a.idx, a.idxM, (int64_t)b * F + f, D, a.idxStride)[d];
             E2[((d & 1) * FpZ + f) * SP + (d >> 1)] = v;
         }
         for (int e = tid; e < 2 * (FpZ - F) * SP; e += NTH) {
@@ -3987,7 +3990,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     }
     // rank-1 input channels: factorised, channel-tiled (its step 1 indexes k over ALL fields: 2 * ceil4(F) <= 64 k values)
     if (l == 0 && conv0_fact_tile_ok(g) && 2 * ((g.F + 3) & ~3) <= 4 * C0T_MAXKS) {
-        if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; }     // rows straight from the outer table (RowSrc)
+        if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; a.idxStride = rs->stride; }     // rows straight from the outer table (RowSrc)
         return launch_conv0_fact_tile_fwd(a, st, wl.w0pack_floats > 0 ? (float*)(w + wl.w0pack) : nullptr);
     }
     if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;                  // cffm_wide_regather_ok() guards the callers
@@ -4173,7 +4176,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         } else {
         pick_nt(g.Pp / 16, &a.qblocks, &NT);
         if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32) {
-            if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
+            if (rs) { a.in = rs->base; a.idx = rs->idx; a.idxM = rs->M; a.idxStride = rs->stride; }
             rc = launch_conv0_fact_tile_wgrad(a, sr.nslab, st);
         }
         else if (l == 0 && rs) { rc = CFFM_ERR_UNSUPPORTED; }
@@ -4213,7 +4216,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
             return rc;
         }
         if (l == 0 && conv0_fact_tile_ok(g) && g.D / 2 <= 32 && 2 * g.F <= 64) {
-            if (rs) { a.Cprev = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
+            if (rs) { a.Cprev = rs->base; a.idx = rs->idx; a.idxM = rs->M; a.idxStride = rs->stride; }
             return launch_conv0_fact_tile_dgrad(a, st, wl.w0pack_floats > 0 ? (float*)(w + wl.w0pack) : nullptr);
         }
         if (l == 0 && rs) return CFFM_ERR_UNSUPPORTED;

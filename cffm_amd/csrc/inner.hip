@@ -73,7 +73,7 @@ int cffm_inner_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int
     }
     InnerBwdArgs a;
     const int nslab = fill_inner_bwd_args(s, theta, ws, B, &a);
-    if (rs) { a.Ei = rs->base; a.idx = rs->idx; a.idxM = rs->M; }
+    if (rs) { a.Ei = rs->base; a.idx = rs->idx; a.idxM = rs->M; a.idxStride = rs->stride; }
     hipLaunchKernelGGL(inner_bwd_kernel, dim3(nslab), dim3(256), lds, (hipStream_t)stream, a);
     CFFM_CHECK_LAUNCH();
     return 0;
@@ -110,6 +110,8 @@ struct GatherInnerWideArgs {
     float *inner_out, *t1, *fb;             // [B], [B][t1w] (columns 0..D-1 = s0), [B][F]
     unsigned long long* keys;               // [B*F] packed (id << 32 | slot) for the sparse update (may be NULL)
     int B, M, F, K, D, P, t1w, act;
+    int row4_in, row4_out, fb_stride;       // 16-byte pieces between rows of inner / outer, floats between rows of fbias (natural: K/4, D/4, 1;
+                                            // the row-sharded step passes its packed records: (K+D+4)/4 twice and K+D+4)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
     const bool is_in = tid < F * K4;
     const int fq = is_in ? tid / K4 : (tid - F * K4) / D4;                // field of the piece
     const int cq = is_in ? tid - fq * K4 : (tid - F * K4) - fq * D4;      // 16-byte piece inside the row
-    const int rowlen4 = FS > 0 ? K4 : (is_in ? K4 : D4);                 // FS > 0: K == D, a compile-time shift
+    const uint32_t rowlen4 = (uint32_t)(is_in ? a.row4_in : a.row4_out);
     const f32x4* tbl = reinterpret_cast<const f32x4*>(is_in ? a.inner : a.outer) + cq;   // this thread's piece of row 0
     // The ids of a phase travel through LDS as well: thread tid < E*F owns slot (e, f) = (tid / F, tid % F) and fetches its id by a
     // 4-byte global_load_lds one phase before the rows that need it are requested; the fetch threads read the ids of their four
@@ -218,11 +220,11 @@ __global__ __launch_bounds__(GIW_T) void gather_inner_fwd_wide_kernel(GatherInne
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 __builtin_amdgcn_global_load_lds(
-                    (const void __attribute__((address_space(1)))*)(tbl + (uint64_t)clampid(idv[e]) * (uint32_t)rowlen4),
+                    (const void __attribute__((address_space(1)))*)(tbl + (uint64_t)clampid(idv[e]) * rowlen4),
                     (void __attribute__((address_space(3)))*)(rows + buf * buf_bytes + e * slot_bytes + wave * 1024), 16, 0, 0);
         }
         if (fo_on)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.fbias + clampid(idsL[ib * 128 + tid])),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.fbias + (uint64_t)clampid(idsL[ib * 128 + tid]) * (uint32_t)a.fb_stride),
                                              (void __attribute__((address_space(3)))*)(fbL + buf * 128 + wave * 64), 4, 0, 0);
     };
     // once the wave's own loads have landed (vmcnt(0)): row sums of the outer rows for the s0 pool - D4 lanes hold one row
@@ -582,7 +584,7 @@ bool cffm_giw_lds_ok() {
 }
 
 int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,
-                               void* ws, hipStream_t stream) {
+                               void* ws, hipStream_t stream, int tab_stride, int tab_rows) {
     if (!cffm_wide_regather_ok(s) || !tab || !ids) return CFFM_ERR_UNSUPPORTED;
     if (B <= 0) return 0;
     cffm_theta_layout_t tl; cffm_ws_layout_t wl;
@@ -593,8 +595,11 @@ int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, 
     a.inner = tab->inner_emb; a.outer = tab->outer_emb; a.fbias = tab->feat_bias; a.ids = ids;
     a.cw = theta + tl.inner_cw; a.cb = theta + tl.inner_cb; a.wd = theta + tl.inner_dw; a.bd = theta + tl.inner_db;
     a.inner_out = (float*)(w + wl.inner_out); a.t1 = (float*)(w + wl.t1); a.fb = (float*)(w + wl.fb);
-    a.keys = (unsigned long long*)(w + wl.sort_keys);
-    a.B = B; a.M = s->M; a.F = g.F; a.K = g.K; a.D = g.D; a.P = g.P; a.t1w = 2 * g.D - 2; a.act = g.act;
+    a.keys = tab_stride > 0 ? nullptr : (unsigned long long*)(w + wl.sort_keys);   // record indices are not update keys
+    a.B = B; a.M = tab_rows > 0 ? tab_rows : s->M; a.F = g.F; a.K = g.K; a.D = g.D; a.P = g.P; a.t1w = 2 * g.D - 2; a.act = g.act;
+    if (tab_stride > 0 && (tab_stride & 3)) return CFFM_ERR_BAD_SHAPE;            // rows are fetched in 16-byte pieces
+    a.row4_in = tab_stride > 0 ? tab_stride / 4 : g.K / 4; a.row4_out = tab_stride > 0 ? tab_stride / 4 : g.D / 4;
+    a.fb_stride = tab_stride > 0 ? tab_stride : 1;
     const int K2 = g.K / 2, NG = GIW_T / K2;
     const int upt = (g.P + NG - 1) / NG;                       // pairs per thread group
     const int npiece = g.F * (g.K / 4 + g.D / 4);
@@ -623,7 +628,7 @@ extern "C" int cffm_gather_inner_fwd(const cffm_shape_t* s, const cffm_tables_t*
     int rc = check_shape(s);
     if (rc) return rc;
     if (!t || !theta || !ids || !ws) return CFFM_ERR_BAD_SHAPE;
-    return cffm_gather_inner_fwd_wide(s, t, theta, ids, B, ws, (hipStream_t)stream);
+    return cffm_gather_inner_fwd_wide(s, t, theta, ids, B, ws, (hipStream_t)stream, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(1024) void inner_bwd_wide_kernel(InnerBwdWideArgs a
     auto fetch = [&](int b, int buf) {
         if (tid < F * K4) {
             const int fr = tid / K4, c = tid - fr * K4;
-            const float* row = row_ptr(a.rows.base, a.rows.idx, a.rows.M, (int64_t)b * F + fr, K);
+            const float* row = row_ptr(a.rows.base, a.rows.idx, a.rows.M, (int64_t)b * F + fr, K, a.rows.stride);
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + 4 * c),
                                              (void __attribute__((address_space(3)))*)(E0 + buf * 32 * K + wave * 256), 16, 0, 0);
         }
@@ -799,7 +804,7 @@ int cffm_inner_bwd_wide(const cffm_shape_t* s, const float* theta, void* ws, int
     InnerBwdArgs o;
     const int nslab = fill_inner_bwd_args(s, theta, ws, B, &o);
     InnerBwdWideArgs a;
-    a.rows.base = rs ? rs->base : o.Ei; a.rows.idx = rs ? rs->idx : nullptr; a.rows.M = rs ? rs->M : 0;
+    a.rows.base = rs ? rs->base : o.Ei; a.rows.idx = rs ? rs->idx : nullptr; a.rows.M = rs ? rs->M : 0; a.rows.stride = rs ? rs->stride : 0;
     a.dout = o.dout; a.out = o.out; a.y = o.y; a.cw = o.cw; a.cb = o.cb; a.wd = o.wd; a.dEi = o.dEi;
     a.slab_cw = o.slab_cw; a.slab_cb = o.slab_cb; a.slab_dw = o.slab_dw; a.slab_db = o.slab_db; a.slab_stride = o.slab_stride;
     a.B = B; a.F = o.g.F; a.K = o.g.K; a.P = o.g.P; a.act = o.g.act; a.loss = o.loss; a.invB = o.invB; a.L = 1.f;

@@ -145,6 +145,7 @@ struct InnerBwdArgs {
     int64_t slab_stride;
     const int32_t* idx = nullptr;                     // non-NULL: Ei is the inner TABLE [M][K] and row (b, f) is idx[b*F+f] (RowSrc)
     int idxM = 0;
+    int idxStride = 0;                                // floats between rows of that table (0 = K): see RowSrc
 };
 static inline size_t inner_bwd_lds(const Geo& g) { return (size_t)(5 * g.F * g.K + g.Pp + 8) * 4; }
 
@@ -197,7 +198,7 @@ __device__ __forceinline__ void inner_bwd_body(const InnerBwdArgs& a, int slab, 
             for (int i = threadIdx.x; i < FK / 4; i += blockDim.x) {
                 const int f = fast_div(i, invK4), c = i - f * K4;
                 reinterpret_cast<float4*>(E)[i] =
-                    reinterpret_cast<const float4*>(row_ptr(Ei, a.idx, a.idxM, (int64_t)b * g.F + f, g.K))[c];
+                    reinterpret_cast<const float4*>(row_ptr(Ei, a.idx, a.idxM, (int64_t)b * g.F + f, g.K, a.idxStride))[c];
             }
         }
         for (int i = threadIdx.x; i < 4 * FK; i += blockDim.x) dE[i] = 0.f;
@@ -280,7 +281,7 @@ static inline int fill_inner_bwd_args(const cffm_shape_t* s, const float* theta,
     a.Ei = (const float*)(w + wl.Ei); a.dout = (const float*)(w + wl.dout);
     a.out = (const float*)(w + wl.out); a.y = nullptr; a.loss = s->loss; a.invB = 1.f / (float)B;
     a.cw = theta + tl.inner_cw; a.cb = theta + tl.inner_cb; a.wd = theta + tl.inner_dw;
-    a.dEi = (float*)(w + wl.dEi); a.idx = nullptr; a.idxM = 0;
+    a.dEi = (float*)(w + wl.dEi); a.idx = nullptr; a.idxM = 0; a.idxStride = 0;
     a.slab_cw = base + tl.inner_cw; a.slab_cb = base + tl.inner_cb; a.slab_dw = base + tl.inner_dw; a.slab_db = base + tl.inner_db;
     a.slab_stride = sr.len;
     return sr.nslab;

@@ -72,8 +72,10 @@ bool cffm_wide_regather_ok(const cffm_shape_t* s);
 bool cffm_giw_lds_ok();     // the fused gather's LDS addressing assumption holds for every instance (inner.hip; checked on the host)
 // tf.nn.embedding_lookup x3 fused with the inner branch, the s0 pool and the first-order inputs: ids -> ws.inner_out,
 // ws.t1[:, 0:D] (s0), ws.fb, ws.sort_keys; Ei / Eo are NOT written
+// tab_stride > 0: the three "tables" are views into ONE array of records of tab_stride floats (the packed rows a row-sharded rank
+// received: tab->inner_emb = records, outer_emb = records + K, feat_bias = records + K + D) with tab_rows records; ids = slot -> record
 int cffm_gather_inner_fwd_wide(const cffm_shape_t* s, const cffm_tables_t* tab, const float* theta, const int32_t* ids, int32_t B,
-                               void* ws, hipStream_t st);
+                               void* ws, hipStream_t st, int tab_stride = 0, int tab_rows = 0);
 int cffm_outer_conv0_fwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);
 int cffm_outer_conv0_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);
 int cffm_inner_bwd_rows(const cffm_shape_t* s, const float* theta, void* ws, int32_t B, const RowSrc* rs, hipStream_t st);

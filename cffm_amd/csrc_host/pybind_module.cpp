@@ -72,6 +72,8 @@ PYBIND11_MODULE(_cffm_pybind, m) {
     CFFM_BIND(cffm_packed_row_floats);
     CFFM_BIND(cffm_gather_packed);
     CFFM_BIND(cffm_stage_packed);
+    CFFM_BIND(cffm_forward_packed);
+    CFFM_BIND(cffm_backward_unscaled_packed);
     CFFM_BIND(cffm_pack_rows_dedup);
     CFFM_BIND(cffm_shard_plan_scratch_bytes);
     CFFM_BIND(cffm_shard_plan);

@@ -376,10 +376,16 @@ class ShardedStep(object):
         # 1) ask the owners for the DISTINCT rows, by their local row index; the answer is one packed record per row
         asked = self._a2a(plan.send_rows[:u], sc, rc)
         got = self._a2a(c.gather_packed(asked), rc, sc)                  # [u, K+D+4] in distinct-id order
-        c.stage_packed(got, plan.pos, B)                                 # duplicates re-expanded: ws.Ei / ws.Eo / ws.fb
-        c.forward_staged(y, B)
-        # 2) local backward without 1/L, gradients keyed by the owner's local row, duplicates summed before they travel
-        grad = c.backward_unscaled(plan.local_ids, y, B, Bg, pack=False)[0]
+        if u > 0 and hasattr(c, 'packed_ok') and c.packed_ok():
+            # wide shapes: the records are consumed where they lie (slot i reads record pos[i] in the kernel that fetches it, the
+            # product-path gather of the replicated tables with a record stride): nothing is staged into ws.Ei / ws.Eo
+            c.forward_packed(got, plan.pos, y, B)
+            grad = c.backward_unscaled_packed(got, plan.pos, y, B, Bg)
+        else:
+            c.stage_packed(got, plan.pos, B)                             # duplicates re-expanded: ws.Ei / ws.Eo / ws.fb
+            c.forward_staged(y, B)
+            # 2) local backward without 1/L, gradients keyed by the owner's local row, duplicates summed before they travel
+            grad = c.backward_unscaled(plan.local_ids, y, B, Bg, pack=False)[0]
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
         rows = c.pack_rows_dedup(plan.local_ids, plan.order, plan.uniq, B)
         recv = self._a2a(rows[:u], sc, rc)

@@ -423,6 +423,28 @@ class HipEngine(object):
         hip.check(self.lib.cffm_stage_packed(self._s, _ptr(packed), _ptr(pos), int(packed.shape[0]), int(B), _ptr(buf),
                                              self._stream()))
 
+    def packed_ok(self):
+        """True when the row-sharded step can consume the packed records where they lie (the wide shapes)."""
+        return bool(self.lib.cffm_gather_inner_fwd_ok(self._s))
+
+    def forward_packed(self, packed, pos, y, B):
+        """Forward half of a row-sharded step straight from the received records [n_records, K+D+4]: slot i reads record pos[i]
+        in the kernel that fetches it; ws.Ei / ws.Eo are never written (cffm_forward_packed)."""
+        buf, _ = self.workspace(B)
+        pos = self._ids(pos.reshape(-1))
+        hip.check(self.lib.cffm_forward_packed(self._s, _ptr(self.theta), _ptr(packed), _ptr(pos), int(packed.shape[0]), _ptr(y),
+                                               int(B), _ptr(buf), self._stream()))
+
+    def backward_unscaled_packed(self, packed, pos, y, B, B_global):
+        """Backward half over the same records (dL/dout = (out - y) / B_global); the row gradients stay in the workspace for
+        pack_rows_dedup.  Returns grad_full [n+4] with this rank's loss-term sum at index n."""
+        buf, _ = self.workspace(B)
+        pos = self._ids(pos.reshape(-1))
+        hip.check(self.lib.cffm_backward_unscaled_packed(self._s, _ptr(self.theta), _ptr(packed), _ptr(pos), int(packed.shape[0]),
+                                                         _ptr(y), int(B), int(B_global), _ptr(buf), _ptr(self._grad_full),
+                                                         self._stream()))
+        return self._grad_full
+
     def forward_staged(self, y, B):
         """cffm_forward over rows that are already staged in the workspace (tab = NULL)."""
         buf, _ = self.workspace(B)

@@ -94,6 +94,8 @@ PROTOTYPES = {
     'cffm_packed_row_floats': (C.c_int32, [_SH]),
     'cffm_gather_packed': (C.c_int, [_SH, _TB, _P, C.c_int64, _P, _P]),
     'cffm_stage_packed': (C.c_int, [_SH, _P, _P, C.c_int64, C.c_int32, _P, _P]),
+    'cffm_forward_packed': (C.c_int, [_SH, _P, _P, _P, C.c_int64, _P, C.c_int32, _P, _P]),
+    'cffm_backward_unscaled_packed': (C.c_int, [_SH, _P, _P, _P, C.c_int64, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     'cffm_pack_rows_dedup': (C.c_int, [_SH, _P, _P, _P, C.c_int32, _P, _P, _P]),
     'cffm_shard_plan_scratch_bytes': (C.c_int64, [C.c_int64]),
     'cffm_shard_plan': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -254,6 +254,15 @@ int cffm_gather_packed(const cffm_shape_t *s, const cffm_tables_t *t, const int3
  * ws.Ei / ws.Eo / ws.fb, ready for cffm_forward(tab = NULL) */
 int cffm_stage_packed(const cffm_shape_t *s, const float *packed, const int32_t *pos, int64_t n_records, int32_t B, void *ws,
                       void *stream);
+/* The same two halves WITHOUT staging, for the wide shapes (cffm_gather_inner_fwd_ok(s); CFFM_ERR_UNSUPPORTED otherwise - use
+ * cffm_stage_packed + cffm_forward(tab = NULL) + cffm_backward_unscaled there): the records are consumed where they lie - slot i reads
+ * record pos[i] in the kernel that fetches it (cffm_gather_inner_fwd_wide with a record stride), the later kernels that need a row again
+ * read it from the records - so ws.Ei / ws.Eo are never written, exactly as cffm_predict / cffm_train_step run on replicated tables.
+ * cffm_backward_unscaled_packed leaves ws.dEi / ws.dEo / ws.dfb for cffm_pack_rows_dedup and this rank's loss-term sum in grad[theta.n]. */
+int cffm_forward_packed(const cffm_shape_t *s, const float *theta, const float *packed, const int32_t *pos, int64_t n_records,
+                        const float *y, int32_t B, void *ws, void *stream);
+int cffm_backward_unscaled_packed(const cffm_shape_t *s, const float *theta, const float *packed, const int32_t *pos,
+                                  int64_t n_records, const float *y, int32_t B, int64_t B_global, void *ws, float *grad, void *stream);
 /* gradient message with the duplicates of one id summed first, in slot order: order int32 [B*F] = slot at sorted position q
  * (sorted by destination, stable), uniq int32 [B*F] = index of the distinct id at position q (non-decreasing), local_ids
  * int32 [B*F] = the owner's row of every slot; ws.dEi / ws.dEo / ws.dfb -> out [#distinct][1+K+D+1] = (row bits | dEi |

@@ -28,12 +28,14 @@ pytestmark = pytest.mark.gpu
 TABLES = ('inner_embeddings', 'outer_embeddings', 'feature_bias')
 
 
-def _case():
+def _case(wide=False):
     cfg = CFFMConfig(M=800, F=10, K=32, D=32, activation='selu')            # the frappe command's shape, small vocabulary
+    if wide:      # F = 16: 120 pairs > 64 channels - the wide-filter kernels, whose row-sharded step consumes the received records in place
+        cfg = CFFMConfig(M=900, F=16, K=32, D=32, activation='relu')
     rng = np.random.default_rng(11)
-    X = rng.integers(0, cfg.M, size=(2, 128, cfg.F)).astype(np.int32)
-    X[:, 70] = X[:, 3]                                                       # the same ids on both ranks: cross-rank duplicates
-    y = rng.choice([-1.0, 1.0], size=(2, 128)).astype(np.float32)
+    X = rng.integers(0, cfg.M, size=(2, 64 if wide else 128, cfg.F)).astype(np.int32)
+    X[:, -20] = X[:, 3]                                                      # the same ids on both ranks: cross-rank duplicates
+    y = rng.choice([-1.0, 1.0], size=X.shape[:2]).astype(np.float32)
     return cfg, X, y
 
 
@@ -53,16 +55,19 @@ def _dp_worker(rank, world, mode):
     return out
 
 
-def _sharded_worker(rank, world, ahead):
+def _sharded_worker(rank, world, ahead, wide=False):
     from cffm_amd.dist import ShardedStep, local_rows_count, shard_params
     from cffm_amd.engine import HipEngine
-    cfg, X, y = _case()
+    cfg, X, y = _case(wide)
     lcfg = copy.copy(cfg)
     lcfg.M = local_rows_count(cfg.M, rank, world)
     eng = HipEngine(lcfg, params=shard_params(init_params(cfg, seed=7), rank, world), device='cuda:0')
     sh = ShardedStep(eng)
     per = X.shape[1] // world
     sl = slice(rank * per, rank * per + per)
+    assert eng.packed_ok() == wide
+    staged, stage = [], eng.stage_packed           # wide: the step must not stage the rows (they are read out of the records)
+    eng.stage_packed = lambda *a: (staged.append(1), stage(*a))[1]
     ids = [torch.from_numpy(X[s, sl].copy()).cuda() for s in range(X.shape[0])]
     ys = [torch.from_numpy(y[s, sl].copy()).cuda() for s in range(X.shape[0])]
     out = []
@@ -71,12 +76,13 @@ def _sharded_worker(rank, world, ahead):
         loss = sh.train_step(ids[s], ys[s], next_ids=nxt)
         torch.cuda.synchronize()
         out.append((float(loss.cpu().reshape(-1)[0]), eng.export_params(), None))
+        assert bool(staged) != wide
     return out, (sh.plans_built, sh.plans_reused)
 
 
-def _single():
+def _single(wide=False):
     from cffm_amd.engine import HipEngine
-    cfg, X, y = _case()
+    cfg, X, y = _case(wide)
     eng = HipEngine(cfg, params=init_params(cfg, seed=7), device='cuda:0')
     out = []
     for s in range(X.shape[0]):
@@ -117,10 +123,12 @@ def test_data_parallel_world2_on_the_gpu_equals_one_engine(mode):
             np.testing.assert_array_equal(np.asarray(res[0][step][1][k]), np.asarray(res[1][step][1][k]), err_msg=k)
 
 
-@pytest.mark.parametrize('ahead', [False, True])
-def test_row_sharded_world2_on_the_gpu_equals_one_engine(ahead):
-    res = H._run(_sharded_worker, 2, ahead)
-    ref = _single()
+@pytest.mark.parametrize('ahead,wide', [(False, False), (True, False), (True, True)])
+def test_row_sharded_world2_on_the_gpu_equals_one_engine(ahead, wide):
+    """wide: the wide-filter shapes run the row-sharded step WITHOUT staging (cffm_forward_packed / cffm_backward_unscaled_packed:
+    the received records are read in place, by record index) - the same non-materialising kernels as the replicated tables."""
+    res = H._run(_sharded_worker, 2, ahead, wide)
+    ref = _single(wide)
     for rank in (0, 1):
         steps, (built, reused) = res[rank]
         assert reused == (1 if ahead else 0) and built == 2
