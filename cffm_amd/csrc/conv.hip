@@ -166,6 +166,142 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, flo
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same K loop on the bf16 MFMA pipe at fp32 accuracy ("bf16x3"): every fp32 operand is split WITHOUT ERROR into three bf16
+// pieces, x = x1 + x2 + x3 (x1 = the top 8 significand bits of x, x2 those of the exact remainder x - x1, x3 those of x - x1 -
+// x2: 24 bits in all, same exponent range as fp32), and a product a*b is taken as the six cross terms of weight >= 2^-16,
+//     a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1),
+// each term an EXACT fp32 value (8 x 8 significand bits) added into the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  What is
+// dropped - a2 b3 + a3 b2 + a3 b3 - is below 2^-23 |a b|: the rounding error of ONE fp32 multiply, against an accumulation
+// over K = 496 .. 1984 terms that both forms round term by term.  Six bf16 MFMAs of 16 cycles do the work of eight fp32 MFMAs of
+// 32 (16x16x4, same output layout): 2.7x on the pipe that bounds the wide shapes (CFFM.py:384-391 at F = 32: 98 % of the step).
+// CFFM_CONV_FP32=1 runs the fp32 MFMA loop above instead (A/B, and the reference the parity of this one was first checked on).
+//
+// Operands: a lane's A operand of a 32-deep step is the two float4 the fp32 loop already loads (k = 4kk .. +3 and 16 + 4kk ..
+// +3 of its row - any assignment of k to lanes is valid as long as B uses the same one); the weight tile lives in LDS as
+// [piece][kk][column][8 bf16]: one ds_read_b128 per (piece, column tile), conflict-free like the fp32 image.
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// two floats -> their three bf16 pieces, packed (low half = first float).  Truncation splits: every remainder is exact.
+__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                              // (hi16(x0), hi16(x1))
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void split8_bf16x3(const float4& lo, const float4& hi, u32x4_t (&p)[3]) {
+    unsigned q[4][3];
+    split_bf16x3(lo.x, lo.y, q[0][0], q[0][1], q[0][2]);
+    split_bf16x3(lo.z, lo.w, q[1][0], q[1][1], q[1][2]);
+    split_bf16x3(hi.x, hi.y, q[2][0], q[2][1], q[2][2]);
+    split_bf16x3(hi.z, hi.w, q[3][0], q[3][1], q[3][2]);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) p[pc] = (u32x4_t){q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int NT>
+constexpr int gemm_b3_lds_bytes() { return 2 * 3 * 4 * NT * 16 * 16; }          // [2 buffers][3 pieces][4 kk][BN columns][16 B]
+
+template <int NT, int RM, bool TRANS, class LoadA>
+__device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, float* Ws, const WSpec w, LoadA loadA, int actA = CFFM_ACT_RELU) {
+    constexpr int BN = NT * 16;
+    constexpr int NREC = 4 * BN;                       // (kk, column) double records of one 32-deep step: 8 k each
+    constexpr int NP = (NREC + 255) / 256;             // double records per thread
+    constexpr int PBUF = 3 * NREC;                     // 16-byte records per LDS buffer
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
+    const int nks = (khalves + 1) >> 1;
+    u32x4_t* Wl = reinterpret_cast<u32x4_t*>(Ws);
+    float4 areg[RM][2], anext[RM][2];
+    float4 w4[NP][2];
+    auto fetchW = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int rec = tid + 256 * i, kq = rec / BN, c = rec - kq * BN;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = ks * KSTEP + 16 * h + 4 * kq, n = w.n0 + c;
+                const bool ok = (NREC % 256 == 0 || rec < NREC) && k < w.k_lim && n < w.n_lim;
+                const int kc = k < w.k_lim ? k : w.k_lim - 4, nc = n < w.n_lim ? n : w.n_lim - 1;
+                float4 v;
+                if (TRANS) {
+                    v = *reinterpret_cast<const float4*>(w.W + (int64_t)nc * w.ld + kc);
+                } else {
+                    const float* src = w.W + (int64_t)kc * w.ld + nc;
+                    v = make_float4(src[0], src[w.ld], src[2 * w.ld], src[3 * w.ld]);
+                }
+                w4[i][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto storeW = [&](u32x4_t* buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int rec = tid + 256 * i;
+            u32x4_t p[3];
+            split8_bf16x3(w4[i][0], w4[i][1], p);
+            if (NREC % 256 == 0 || rec < NREC) {
+                buf[rec] = p[0]; buf[NREC + rec] = p[1]; buf[2 * NREC + rec] = p[2];
+            }
+        }
+    };
+    loadA(0, areg);
+    fetchW(0);
+    __syncthreads();                          // previous users of Ws are done
+    storeW(Wl);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;
+        if (more) {
+            loadA(ks + 1, anext);
+            fetchW(ks + 1);
+        }
+        if (actA != CFFM_ACT_RELU && actA != CFFM_ACT_PRELU && actA != CFFM_ACT_ELU) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) act_pos4(areg[rm][h], actA);
+        }
+        u32x4_t ap[RM][3];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) split8_bf16x3(areg[rm][0], areg[rm][1], ap[rm]);
+        // (an odd last step: the B records of its second half are zeros - fetchW fills k >= k_lim with zeros - and the A values
+        //  there are finite numbers read from a clamped address)
+        const u32x4_t* Wb = Wl + (ks & 1) * PBUF + kk * BN + r;
+        // two column tiles at a time: 2 * RM independent accumulation chains, so that consecutive MFMAs never wait on each other
+        static_assert(NT % 2 == 0, "column tiles are taken in pairs");
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) {
+            u32x4_t b[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[u][pc] = Wb[pc * NREC + (nt + u) * 16];
+            // (A piece, B piece) of the six terms, the small ones first
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int rm = 0; rm < RM; ++rm) acc[rm][nt + u] = mfma_bf16(ap[rm][TA[t]], b[u][TB[t]], acc[rm][nt + u]);
+        }
+        if (more) {
+            storeW(Wl + ((ks + 1) & 1) * PBUF);
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) { areg[rm][0] = anext[rm][0]; areg[rm][1] = anext[rm][1]; }
+        }
+        __syncthreads();
+    }
+}
+
 // stage the embedding rows of examples [b0, b0 + n_ex) into LDS with row pitch Dp = D + 1
 __device__ __forceinline__ void stage_examples(float* Es, const float* __restrict__ Eo, int b0, int n_ex, int B,
                                                int F, int D, int Dp) {
@@ -197,12 +333,14 @@ struct ConvArgs {
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
 // accumulation registers = 2 per SIMD without the bound): 12.93 -> 12.33 ms per launch at the stress shape.
-template <int NT, int RM, bool GEN>
+// B3: the K loop on the bf16 pipe (gemm_tile_b3); everything around it - operand addressing, epilogue, pools, masks - is the same
+template <int NT, int RM, bool GEN, bool B3 = false>
 __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ws = reinterpret_cast<float*>(smem);                    // [2][32][LDW]
-    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + 2 * KSTEP * LDW);   // [Pp]   (GEN)
+    float* Ws = reinterpret_cast<float*>(smem);                    // [2][32][LDW]  (B3: [2][3][4][BN] 16-byte records)
+    static_assert(!B3 || !GEN, "the bf16x3 loop serves the direct layers");
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + (B3 ? gemm_b3_lds_bytes<NT>() / 4 : 2 * KSTEP * LDW));   // [Pp]   (GEN)
     float* Es = reinterpret_cast<float*>(lut + a.Pp);             // [n_ex][F][Dp] (GEN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1;
@@ -272,7 +410,8 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, GEN ? CFFM_ACT_RELU : a.act);   // act(C_{l-1}) on the A operand
+    if constexpr (B3) gemm_tile_b3<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, a.act);
+    else gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, GEN ? CFFM_ACT_RELU : a.act);   // act(C_{l-1}) on the A operand
 
     float psum[RM][4];                                         // pool partials: this lane's column of every row it holds
 #pragma unroll
@@ -353,12 +492,13 @@ struct DgradArgs {
 
 // 3 wavefronts per SIMD for the 128 x 128 instance (166 VGPRs instead of 200, nothing spilled): 16.36 -> 14.80 ms per launch at
 // the stress shape.  (wgrad2_kernel<8> at the same bound spills 189 registers and stays at 2.)
-template <int NT, int RM, bool L0>
+template <int NT, int RM, bool L0, bool B3 = false>
 __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgrad_kernel(DgradArgs a) {
     constexpr int BN = NT * 16, LDW = BN + 4, BM = 64 * RM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!B3 || !L0, "the bf16x3 loop serves the direct layers");
     float* Ws = reinterpret_cast<float*>(smem);
-    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + 2 * KSTEP * LDW);   // L0 only from here on
+    uint32_t* lut = reinterpret_cast<uint32_t*>(Ws + (B3 ? gemm_b3_lds_bytes<NT>() / 4 : 2 * KSTEP * LDW));   // L0 only from here on
     float* Es = reinterpret_cast<float*>(lut + a.Pp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kk = lane >> 4;
     const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp, P = a.P, Dp = a.D + 1, S2 = So * So;
@@ -423,7 +563,8 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
             for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
+            if constexpr (B3) gemm_tile_b3<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
+            else gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
 
             // ---- epilogue ------------------------------------------------------------------------
             if (!L0) {
@@ -2435,18 +2576,33 @@ static inline int set_lds(KernelT k, size_t lds) {
     return 0;
 }
 
+// bf16x3 K loop for the 128 x 128 instance of the direct layers (the one the wide shapes run); CFFM_CONV_FP32=1: the fp32 MFMA loop
+static inline bool conv_b3_on() {
+    static const bool on = getenv("CFFM_CONV_FP32") == nullptr;
+    return on;
+}
 template <int NT, int RM, bool GEN>
 static int launch_conv_fwd(const ConvArgs& a, int nblk, hipStream_t st) {
     constexpr int BM = 64 * RM;
     const int S2 = 1 << (2 * a.lgSo);
     const int n_ex = GEN ? (BM > S2 ? BM / S2 : 1) : 0;
-    const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 0) + 4) * 4;
-    int rc = set_lds(conv_fwd_kernel<NT, RM, GEN>, lds);
-    if (rc) return rc;
     ConvArgs b = a;
     b.nblk = nblk;
     const int64_t nb1 = 8 * xcd_per((a.Mtot + BM - 1) / BM) * nblk;
     if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+    if constexpr (NT == 8 && RM == 2 && !GEN) {
+        if (conv_b3_on()) {
+            const size_t lds3 = (size_t)gemm_b3_lds_bytes<NT>() + 16;
+            int rc3 = set_lds(conv_fwd_kernel<NT, RM, GEN, true>, lds3);
+            if (rc3) return rc3;
+            hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN, true>), dim3((unsigned)nb1), dim3(256), lds3, st, b);
+            CFFM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (GEN ? a.Pp + n_ex * a.F * (a.D + 1) : 0) + 4) * 4;
+    int rc = set_lds(conv_fwd_kernel<NT, RM, GEN>, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN>), dim3((unsigned)nb1), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
@@ -2459,12 +2615,22 @@ static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
     const int rows_per_wg = L0 ? (S2 > BM ? S2 : BM) : BM;
     const int n_ex = L0 ? rows_per_wg / S2 : 0;
     const size_t lds = (size_t)(2 * KSTEP * (NT * 16 + 4) + (L0 ? a.Pp + 5 * n_ex * a.F * (a.D + 1) + 2 * n_ex * a.F : 0) + 4) * 4;
-    int rc = set_lds(dgrad_kernel<NT, RM, L0>, lds);
-    if (rc) return rc;
     DgradArgs b = a;
     b.nblk = L0 ? 1 : nblk;
     const int64_t nb1 = 8 * xcd_per((a.Mtot + rows_per_wg - 1) / rows_per_wg) * b.nblk;
     if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
+    if constexpr (NT == 8 && RM == 2 && !L0) {
+        if (conv_b3_on()) {
+            const size_t lds3 = (size_t)gemm_b3_lds_bytes<NT>() + 16;
+            int rc3 = set_lds(dgrad_kernel<NT, RM, L0, true>, lds3);
+            if (rc3) return rc3;
+            hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0, true>), dim3((unsigned)nb1), dim3(256), lds3, st, b);
+            CFFM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    int rc = set_lds(dgrad_kernel<NT, RM, L0>, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0>), dim3((unsigned)nb1), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
