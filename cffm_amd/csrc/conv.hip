@@ -1035,6 +1035,153 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgradArgs a) {
     if (ib == 0 && tid < BQ && q0 + tid < Pp) a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = bsum;
 }
 
+// wgrad3: the same weight gradient on the bf16 MFMA pipe at fp32 accuracy (bf16x3, see gemm_tile_b3): both operands are split
+// without error into three bf16 pieces WHILE THEY ARE STAGED, the LDS images hold [piece][m-octet][channel] records of 8 bf16
+// (8 consecutive reduction rows of one channel: one ds_read_b128 = the operand of one v_mfma_f32_16x16x32_bf16), and the six
+// cross terms of weight >= 2^-16 are accumulated in fp32.  One 32-row step per barrier pair (48 KB of LDS: three workgroups per
+// CU cover each other's staging); waves 0-1 stage A' = act(C_{l-1}) patches, waves 2-3 stage dC and keep the bias gradient.
+template <int NT>
+__global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
+    constexpr int RI = 2, BI = 64 * RI, BQ = NT * 16, KM = 32, NO = KM / 8;
+    static_assert(BI / 4 * NO == 128 && BQ / 4 * NO <= 128, "one 8-row x 4-channel block per staging thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4_t* As = reinterpret_cast<u32x4_t*>(smem);                   // [3][NO][BI]
+    u32x4_t* Bs = As + 3 * NO * BI;                                   // [3][NO][BQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
+    const int So = 1 << a.lgSo, Sin = 2 * So, Pp = a.Pp;
+    const float invPp = 1.f / (float)Pp;
+    const int64_t tile = xcd_tile(xcd_per(a.nslab) * a.nxy);
+    if (tile >= (int64_t)a.nslab * a.nxy) return;
+    const int slab = (int)(tile / a.nxy), bxy = (int)(tile % a.nxy);
+    const int ib = bxy / a.qblocks, qb = bxy - ib * a.qblocks;
+    const int i0 = ib * BI, q0 = qb * BQ;
+    const int nvalid = min(NT, (Pp - q0) / 16);
+    const int64_t nsteps = (a.Mtot + KM - 1) / KM;
+    const int64_t cps = (nsteps + a.nslab - 1) / a.nslab;
+    const int64_t s_lo = slab * cps, s_hi = min(nsteps, s_lo + cps);
+
+    // staging role of this thread (fixed over the steps): an 8-row x 4-channel block of A' (waves 0, 1) or of dC (waves 2, 3)
+    const bool stA = wave < 2;
+    const int pb = tid & 127;
+    const int oct = stA ? pb / (BI / 4) : pb / (BQ / 4), c4 = stA ? pb % (BI / 4) : pb % (BQ / 4);
+    const bool stOn = stA || pb < NO * (BQ / 4);
+    int a_off = -1;                                                   // A': float offset of (tap, p) inside a patch, or -1 (zeros)
+    if (stA) {
+        const int ii = i0 + 4 * c4, tap = fast_div(ii, invPp), p = ii - tap * Pp;
+        a_off = tap < 4 ? ((tap >> 1) * Sin + (tap & 1)) * Pp + p : -1;
+    }
+    const int qcol = q0 + 4 * c4;                                     // dC: first channel of the block
+    f32x4 acc[RI][NT];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ri][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 reg[8];
+
+    auto fetch = [&](int64_t st) {            // global -> registers for step st (unconditional loads from clamped addresses)
+        const int64_t mbase = st * KM + 8 * oct;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int64_t m = mbase + t;
+            const int64_t mc = m < a.Mtot ? m : a.Mtot - 1;
+            float4 v;
+            bool ok;
+            if (stA) {
+                const RowPos rp = row_pos(mc, a.lgSo);
+                const int64_t pos = (((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp + (a_off >= 0 ? a_off : 0);
+                v = *reinterpret_cast<const float4*>(a.in + pos);
+                ok = m < a.Mtot && a_off >= 0;
+            } else {
+                v = *reinterpret_cast<const float4*>(a.dC + mc * Pp + (qcol < Pp ? qcol : Pp - 4));
+                ok = stOn && m < a.Mtot && qcol < Pp;
+            }
+            reg[t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // the 8 x 4 block -> per channel the 8 reduction rows as three 8-bf16 records
+    auto stage = [&]() {
+        if (stA && a.act != CFFM_ACT_RELU && a.act != CFFM_ACT_PRELU && a.act != CFFM_ACT_ELU) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) act_pos4(reg[t], a.act);                  // A' = act(C_{l-1}), C >= 0
+        }
+        if (!stA) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { bsum[0] += reg[t].x; bsum[1] += reg[t].y; bsum[2] += reg[t].z; bsum[3] += reg[t].w; }
+        }
+        u32x4_t* dst = stA ? As + oct * BI + 4 * c4 : Bs + oct * BQ + 4 * c4;
+        const int pstride = stA ? NO * BI : NO * BQ;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = ch == 0 ? reg[t].x : ch == 1 ? reg[t].y : ch == 2 ? reg[t].z : reg[t].w;
+            u32x4_t p[3];
+            split8_bf16x3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p);
+            if (stOn) { dst[ch] = p[0]; dst[pstride + ch] = p[1]; dst[2 * pstride + ch] = p[2]; }
+        }
+    };
+
+    if (s_lo < s_hi) fetch(s_lo);
+    for (int64_t st = s_lo; st < s_hi; ++st) {
+        __syncthreads();                                   // previous step's LDS reads are done
+        stage();
+        __syncthreads();
+        if (st + 1 < s_hi) fetch(st + 1);                 // in flight while this step's MFMAs run
+        // ---- MFMA: one 32-deep group; lane (r, kk) takes m-octet kk -----------------------------------------------------
+        u32x4_t af[RI][3];
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[ri][pc] = As[(pc * NO + kk) * BI + (wave * RI + ri) * 16 + r];
+        static_assert(NT % 2 == 0, "column tiles are taken in pairs");
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) {
+            u32x4_t bf[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bf[u][pc] = Bs[(pc * NO + kk) * BQ + (nt + u) * 16 + r];
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // the small terms first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) acc[ri][nt + u] = mfma_bf16(af[ri][TA[t]], bf[u][TB[t]], acc[ri][nt + u]);
+        }
+    }
+    // ---- write this slab (every element of the parameter range, zeros included) ---------------------
+    float* sw = a.slabW + (int64_t)slab * a.slab_stride;
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nvalid) continue;
+            const int q = q0 + nt * 16 + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + (wave * RI + ri) * 16 + kk * 4 + j;
+                if (i < 4 * Pp) sw[(int64_t)i * Pp + q] = acc[ri][nt][j];
+            }
+        }
+    if (ib == 0) {                                          // db[q]: the NO octet partials of every channel, in octet order
+        float* red = reinterpret_cast<float*>(smem);        // [NO][BQ]
+        __syncthreads();
+        if (!stA && stOn) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) red[oct * BQ + 4 * c4 + ch] = bsum[ch];
+        }
+        __syncthreads();
+        if (tid < BQ && q0 + tid < Pp) {
+            float v = red[tid];
+#pragma unroll
+            for (int o = 1; o < NO; ++o) v += red[o * BQ + tid];
+            a.slabB[(int64_t)slab * a.slab_stride + q0 + tid] = v;
+        }
+    }
+}
+
 // =================================================================================================
 // Tap-split kernels for small channel counts (Pp = 16*NT <= 64, i.e. F <= 11: frappe, book-crossing, ml-tag).
 //
@@ -2656,12 +2803,22 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 template <int NT>
 static int launch_wgrad2(const WgradArgs& a, hipStream_t st) {
     constexpr int BI = 128, BQ = NT * 16;
-    const size_t lds = (size_t)(WG_KM * BI + WG_KM * BQ) * 4 + 16;
-    int rc = set_lds(wgrad2_kernel<NT>, lds);
-    if (rc) return rc;
     WgradArgs b = a;
     b.nslab = CFFM_NSLAB;                                                       // Pp > 64: conv_slabs() == CFFM_NSLAB
     b.nxy = ((4 * a.Pp + BI - 1) / BI) * a.qblocks;
+    if constexpr (NT == 8) {
+        if (conv_b3_on()) {                                 // the same tile on the bf16 pipe (bf16x3 split, fp32 accumulate)
+            const size_t lds3 = (size_t)3 * 4 * (BI + BQ) * 16 + 16;
+            int rc3 = set_lds(wgrad3_kernel<NT>, lds3);
+            if (rc3) return rc3;
+            hipLaunchKernelGGL((wgrad3_kernel<NT>), dim3((unsigned)(8 * xcd_per(b.nslab) * b.nxy)), dim3(256), lds3, st, b);
+            CFFM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    const size_t lds = (size_t)(WG_KM * BI + WG_KM * BQ) * 4 + 16;
+    int rc = set_lds(wgrad2_kernel<NT>, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL((wgrad2_kernel<NT>), dim3((unsigned)(8 * xcd_per(b.nslab) * b.nxy)), dim3(256), lds, st, b);
     CFFM_CHECK_LAUNCH();
     return 0;
