@@ -104,6 +104,10 @@ extern "C" int cffm_ws_layout(const cffm_shape_t* s, int32_t B, cffm_ws_layout_t
             if (g.live > 1 && g.act != CFFM_ACT_GELU)        // relu mask of C[0] (gelu's derivative needs the value)
                 out->relu0 = take(relu_mask_off(g, b, g.live - 1));       // masks of C_0 .. C_{live-2}
         }
+        if (g.Pp > 64 && g.live > 1) {                           // the bf16x3 loops of the direct layers: one pre-split filter image
+            out->wb3_bytes = cffm_wb3_bytes(g.Pp);
+            out->wb3 = take(out->wb3_bytes);
+        }
     }
     out->bytes = o;
     return 0;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void act_pos4(float4& c, int act) {
     }
 }
 
-struct WSpec { const float* W; int ld, k_lim, n_lim, n0; };
+struct WSpec { const float* W; int ld, k_lim, n_lim, n0; const void* pre = nullptr; int npad = 0; };   // pre / npad: gemm_tile_b3's pre-split image
 
 template <int NT, int RM, bool TRANS, class LoadA>
 __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[RM][NT], int khalves, float* Ws, const WSpec w, LoadA loadA, int actA = CFFM_ACT_RELU) {
@@ -214,54 +214,35 @@ template <int NT, int RM, bool TRANS, class LoadA>
 __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, float* Ws, const WSpec w, LoadA loadA, int actA = CFFM_ACT_RELU) {
     constexpr int BN = NT * 16;
     constexpr int NREC = 4 * BN;                       // (kk, column) double records of one 32-deep step: 8 k each
-    constexpr int NP = (NREC + 255) / 256;             // double records per thread
     constexpr int PBUF = 3 * NREC;                     // 16-byte records per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
     const int nks = (khalves + 1) >> 1;
     u32x4_t* Wl = reinterpret_cast<u32x4_t*>(Ws);
     float4 areg[RM][2], anext[RM][2];
-    float4 w4[NP][2];
-    auto fetchW = [&](int ks) {
+    // The weight tile is split ONCE per launch (pack_w_b3_kernel, w.pre) into the very records this loop reads,
+    // [k-step][piece][kk][padded column]: a step's tile is 12 rows of BN records = 24 wave-sized pieces that go global -> LDS by
+    // DMA (global_load_lds_dwordx4, six per wave) - no staging registers, no split instructions, no ds_write in the loop.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dmaW = [&](int ks, u32x4_t* buf) {
+        static_assert(BN == 128, "six 1 KB pieces per wave");
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(w.pre) + (int64_t)ks * 12 * w.npad + w.n0 + lane;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int rec = tid + 256 * i, kq = rec / BN, c = rec - kq * BN;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = ks * KSTEP + 16 * h + 4 * kq, n = w.n0 + c;
-                const bool ok = (NREC % 256 == 0 || rec < NREC) && k < w.k_lim && n < w.n_lim;
-                const int kc = k < w.k_lim ? k : w.k_lim - 4, nc = n < w.n_lim ? n : w.n_lim - 1;
-                float4 v;
-                if (TRANS) {
-                    v = *reinterpret_cast<const float4*>(w.W + (int64_t)nc * w.ld + kc);
-                } else {
-                    const float* src = w.W + (int64_t)kc * w.ld + nc;
-                    v = make_float4(src[0], src[w.ld], src[2 * w.ld], src[3 * w.ld]);
-                }
-                w4[i][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto storeW = [&](u32x4_t* buf) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int rec = tid + 256 * i;
-            u32x4_t p[3];
-            split8_bf16x3(w4[i][0], w4[i][1], p);
-            if (NREC % 256 == 0 || rec < NREC) {
-                buf[rec] = p[0]; buf[NREC + rec] = p[1]; buf[2 * NREC + rec] = p[2];
-            }
+        for (int i = 0; i < 6; ++i) {
+            const int j = wave * 6 + i, row = j >> 1, half = j & 1;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (int64_t)row * w.npad + half * 64),
+                                             (void __attribute__((address_space(3)))*)(buf + row * BN + half * 64), 16, 0, 0);
         }
     };
     loadA(0, areg);
-    fetchW(0);
     __syncthreads();                          // previous users of Ws are done
-    storeW(Wl);
+    dmaW(0, Wl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ks = 0; ks < nks; ++ks) {
         const bool more = ks + 1 < nks;
         if (more) {
             loadA(ks + 1, anext);
-            fetchW(ks + 1);
+            dmaW(ks + 1, Wl + ((ks + 1) & 1) * PBUF);              // that buffer was last read in step ks - 1, behind a barrier
         }
         if (actA != CFFM_ACT_RELU && actA != CFFM_ACT_PRELU && actA != CFFM_ACT_ELU) {
 #pragma unroll
@@ -272,7 +253,7 @@ __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, 
         u32x4_t ap[RM][3];
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) split8_bf16x3(areg[rm][0], areg[rm][1], ap[rm]);
-        // (an odd last step: the B records of its second half are zeros - fetchW fills k >= k_lim with zeros - and the A values
+        // (an odd last step: the B records of its second half are zeros - the image is zero beyond k_lim - and the A values
         //  there are finite numbers read from a clamped address)
         const u32x4_t* Wb = Wl + (ks & 1) * PBUF + kk * BN + r;
         // two column tiles at a time: 2 * RM independent accumulation chains, so that consecutive MFMAs never wait on each other
@@ -294,12 +275,55 @@ __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, 
                     for (int rm = 0; rm < RM; ++rm) acc[rm][nt + u] = mfma_bf16(ap[rm][TA[t]], b[u][TB[t]], acc[rm][nt + u]);
         }
         if (more) {
-            storeW(Wl + ((ks + 1) & 1) * PBUF);
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) { areg[rm][0] = anext[rm][0]; areg[rm][1] = anext[rm][1]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the next tile have landed
         }
         __syncthreads();
     }
+}
+
+// The weight tile of gemm_tile_b3 split once per launch: image [k-step][piece][kk][npad columns] of 8-bf16 records, record
+// (ks, kk, n) = the three pieces of element (k, n) for k = 32 ks + 16 h + 4 kk + t (h = 0, 1; t = 0 .. 3) in the order the loop's A
+// operand uses; zeros beyond k_lim / n_lim.  TRANS as in WSpec.  One thread per record: ~6 MB per layer, a few microseconds.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void pack_w_b3_kernel(const float* __restrict__ W, int ld, int k_lim, int n_lim, int npad, int nks,
+                                                        u32x4_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)nks * 4 * npad;
+    if (idx >= total) return;
+    const int n = (int)(idx % npad), kk = (int)((idx / npad) & 3), ks = (int)(idx / ((int64_t)4 * npad));
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = ks * KSTEP + 16 * h + 4 * kk + t;
+            const bool ok = k < k_lim && n < n_lim;
+            const int kc = k < k_lim ? k : k_lim - 1, nc = n < n_lim ? n : n_lim - 1;
+            const float x = TRANS ? W[(int64_t)nc * ld + kc] : W[(int64_t)kc * ld + nc];
+            v[4 * h + t] = ok ? x : 0.f;
+        }
+    u32x4_t p[3];
+    split8_bf16x3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p);
+    const int64_t o = ((int64_t)ks * 12 + kk) * npad + n;
+    out[o] = p[0]; out[o + (int64_t)4 * npad] = p[1]; out[o + (int64_t)8 * npad] = p[2];
+}
+static inline int64_t wb3_image_bytes(int K, int N) {        // K = reduction length, N = columns of the weight operand
+    return (int64_t)((K + KSTEP - 1) / KSTEP) * 12 * ((N + 127) / 128 * 128) * 16;
+}
+int64_t cffm_wb3_bytes(int Pp) {
+    const int64_t f = wb3_image_bytes(4 * Pp, Pp), d = wb3_image_bytes(Pp, 4 * Pp);
+    return f > d ? f : d;
+}
+template <bool TRANS>
+static int pack_w_b3(const float* W, int ld, int K, int N, void* out, hipStream_t st) {
+    const int nks = (K + KSTEP - 1) / KSTEP, npad = (N + 127) / 128 * 128;
+    const int64_t total = (int64_t)nks * 4 * npad;
+    hipLaunchKernelGGL((pack_w_b3_kernel<TRANS>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, ld, K, N, npad, nks,
+                       (u32x4_t*)out);
+    CFFM_CHECK_LAUNCH();
+    return 0;
 }
 
 // stage the embedding rows of examples [b0, b0 + n_ex) into LDS with row pitch Dp = D + 1
@@ -329,6 +353,8 @@ struct ConvArgs {
     float* pool = nullptr;          // wide shapes: partial sum pools of act(out), [B][So][pool_np] (pool_partials(), common.hpp)
     int pool_np = 0;
     uint16_t* relu = nullptr;       // wide shapes (tiled layer-0 forward, conv_fwd_kernel): bit mask of out > 0, [B*So*So][Pp/16] 16-bit words (ws.relu0)
+    void* wb3 = nullptr;            // bf16x3 instance: scratch for the pre-split filter image (ws.wb3; NULL: split while staging)
+    int wb3_npad = 0;
 };
 
 // The 128 x 128 instance of the wide shapes is held to 3 wavefronts per SIMD (166 VGPRs, nothing spilled; it took 106 + 96
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
             }
         }
     };
-    const WSpec wspec = {a.W, Pp, 4 * Pp, Pp, n0};
+    const WSpec wspec = {a.W, Pp, 4 * Pp, Pp, n0, B3 ? a.wb3 : nullptr, a.wb3_npad};
 
     f32x4 acc[RM][NT];
 #pragma unroll
@@ -488,6 +514,8 @@ struct DgradArgs {
     int idxM = 0;
     int idxStride = 0;              // floats between rows of the table (0 = D): see RowSrc
     const uint16_t* relu = nullptr; // dgrad_kernel, L0 = false: bit mask of C_{l-1} > 0 ([rows of C_{l-1}][Pp/16] words) read INSTEAD of C_{l-1}
+    void* wb3 = nullptr;            // bf16x3 instance: scratch for the pre-split (transposed) filter image (ws.wb3)
+    int wb3_npad = 0;
 };
 
 // 3 wavefronts per SIMD for the 128 x 128 instance (166 VGPRs instead of 200, nothing spilled): 16.36 -> 14.80 ms per launch at
@@ -557,7 +585,7 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
                         reg[rm][h] = *reinterpret_cast<const float4*>(a.dC + arow[rm] + (k < Pp ? k : Pp - 16));
                 }
             };
-            const WSpec wspec = {a.W, Pp, Pp, Ntot, n0};        // W^T tile: (k = q, n) = W[n][q], 16-byte reads along q
+            const WSpec wspec = {a.W, Pp, Pp, Ntot, n0, B3 ? a.wb3 : nullptr, a.wb3_npad};        // W^T tile: (k = q, n) = W[n][q], 16-byte reads along q
             f32x4 acc[RM][NT];
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm)
@@ -2738,10 +2766,12 @@ static int launch_conv_fwd(const ConvArgs& a, int nblk, hipStream_t st) {
     const int64_t nb1 = 8 * xcd_per((a.Mtot + BM - 1) / BM) * nblk;
     if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
     if constexpr (NT == 8 && RM == 2 && !GEN) {
-        if (conv_b3_on()) {
+        if (conv_b3_on() && b.wb3 != nullptr) {
             const size_t lds3 = (size_t)gemm_b3_lds_bytes<NT>() + 16;
             int rc3 = set_lds(conv_fwd_kernel<NT, RM, GEN, true>, lds3);
             if (rc3) return rc3;
+            b.wb3_npad = (a.Pp + 127) / 128 * 128;        // the filter changes every step: split it once for this launch
+            if ((rc3 = pack_w_b3<false>(a.W, a.Pp, 4 * a.Pp, a.Pp, b.wb3, st))) return rc3;
             hipLaunchKernelGGL((conv_fwd_kernel<NT, RM, GEN, true>), dim3((unsigned)nb1), dim3(256), lds3, st, b);
             CFFM_CHECK_LAUNCH();
             return 0;
@@ -2767,10 +2797,12 @@ static int launch_dgrad(const DgradArgs& a, int nblk, hipStream_t st) {
     const int64_t nb1 = 8 * xcd_per((a.Mtot + rows_per_wg - 1) / rows_per_wg) * b.nblk;
     if (nb1 > 0x7fffffffll) return CFFM_ERR_UNSUPPORTED;
     if constexpr (NT == 8 && RM == 2 && !L0) {
-        if (conv_b3_on()) {
+        if (conv_b3_on() && b.wb3 != nullptr) {
             const size_t lds3 = (size_t)gemm_b3_lds_bytes<NT>() + 16;
             int rc3 = set_lds(dgrad_kernel<NT, RM, L0, true>, lds3);
             if (rc3) return rc3;
+            b.wb3_npad = (4 * a.Pp + 127) / 128 * 128;
+            if ((rc3 = pack_w_b3<true>(a.W, a.Pp, a.Pp, 4 * a.Pp, b.wb3, st))) return rc3;
             hipLaunchKernelGGL((dgrad_kernel<NT, RM, L0, true>), dim3((unsigned)nb1), dim3(256), lds3, st, b);
             CFFM_CHECK_LAUNCH();
             return 0;
@@ -4285,6 +4317,7 @@ static int conv_fwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
     a.Mtot = layer_rows(g, B, l, &a.lgSo);
     a.B = B; a.P = g.P; a.Pp = g.Pp; a.F = g.F; a.D = g.D; a.act = g.act;
     if (wl.pool_np[l] > 0) { a.pool = (float*)(w + wl.pool[l]); a.pool_np = wl.pool_np[l]; }   // wide shapes: the epilogue leaves the pool partials
+    if (l >= 1 && wl.wb3_bytes > 0) a.wb3 = (void*)(w + wl.wb3);
     if (wl.relu0 > 0 && l + 1 < g.live) a.relu = (uint16_t*)(w + wl.relu0 + relu_mask_off(g, B, l));   // ... and the relu mask of C_l for the input gradient of layer l+1
     int nblk, NT;
     int rc = 0;
@@ -4517,6 +4550,7 @@ static int conv_bwd_any(const cffm_shape_t* s, const float* theta, void* ws, int
         a.Cprev = (const float*)(w + (l == 0 ? wl.Eo : wl.C[l - 1]));
         a.dt1 = (const float*)(w + wl.dt1);
         a.dprev = (float*)(w + (l == 0 ? wl.dEo : wl.dC[l - 1]));
+        if (l >= 1 && wl.wb3_bytes > 0) a.wb3 = (void*)(w + wl.wb3);
         {   // wide shapes: the relu mask the forward of layer l-1 left (1/32 of the bytes of C_{l-1})
             const char* oldfwd = getenv("CFFM_TILE_FWD");
             if (l >= 1 && wl.relu0 > 0 && !(l == 1 && oldfwd && oldfwd[0] == '1') && !getenv("CFFM_DGRAD_NO_MASK"))

@@ -69,6 +69,7 @@ int cffm_apply_opt(const cffm_shape_t* s, const cffm_tables_t* tab, const cffm_t
 
 // ---- wide shapes (Pp > 64): rows consumed where they are fetched, nothing materialised (RowSrc, common.hpp) ---------------
 bool cffm_wide_regather_ok(const cffm_shape_t* s);
+int64_t cffm_wb3_bytes(int Pp);     // bytes of the pre-split filter image of the bf16x3 conv loops (conv.hip), forward or input gradient
 bool cffm_giw_lds_ok();     // the fused gather's LDS addressing assumption holds for every instance (inner.hip; checked on the host)
 // tf.nn.embedding_lookup x3 fused with the inner branch, the s0 pool and the first-order inputs: ids -> ws.inner_out,
 // ws.t1[:, 0:D] (s0), ws.fb, ws.sort_keys; Ei / Eo are NOT written

@@ -50,7 +50,8 @@ class WsLayout(C.Structure):
                 ('gpart', C.c_int64), ('gpart_floats', C.c_int64), ('sort_keys', C.c_int64), ('sort_vals', C.c_int64),
                 ('sort_tmp', C.c_int64), ('sort_tmp_bytes', C.c_int64), ('Gi', C.c_int64), ('Go', C.c_int64), ('Gfb', C.c_int64),
                 ('pool', C.c_int64 * MAX_LAYERS), ('pool_np', C.c_int32 * MAX_LAYERS),
-                ('w0pack', C.c_int64), ('w0pack_floats', C.c_int64), ('relu0', C.c_int64)]
+                ('w0pack', C.c_int64), ('w0pack_floats', C.c_int64), ('relu0', C.c_int64),
+                ('wb3', C.c_int64), ('wb3_bytes', C.c_int64)]
 
 
 class Tables(C.Structure):

@@ -112,6 +112,10 @@ typedef struct cffm_ws_layout {
                                                C[l] > 0 (16-bit words, [B*S_l*S_l][Pp/16] per layer, one layer after the other), written
                                                by the forward of layer l and read by the input gradient of layer l+1 instead of C[l]
                                                itself (0 = not used)                                                               */
+    int64_t wb3;                            /* wide shapes: scratch for ONE conv filter split into three bf16 pieces in the record order
+                                               of the bf16x3 contraction ([k-step][piece][kk][padded column] x 16 bytes; rebuilt in front
+                                               of every direct conv forward / input-gradient launch; 0 = not used)                     */
+    int64_t wb3_bytes;
 } cffm_ws_layout_t;
 
 typedef struct cffm_tables {                /* the three gathered variables and nothing else       */
