@@ -24,6 +24,8 @@
 
 #include "internal.hpp"
 
+#include <type_traits>
+
 #include <stdlib.h>
 #include "inner_body.hpp"
 #include "head_body.hpp"
@@ -210,7 +212,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4_t& a, const u32x4_t& b, c
 template <int NT>
 constexpr int gemm_b3_lds_bytes() { return 2 * 3 * 4 * NT * 16 * 16; }          // [2 buffers][3 pieces][4 kk][BN columns][16 B]
 
-template <int NT, int RM, bool TRANS, class LoadA>
+// ACTA: the A operand goes through act_pos4(actA) first (selu / gelu on the stored relu output); false: relu / prelu / elu, the
+// identity there - a compile-time flag, so that the main loop of the common case is branch-free
+template <int NT, int RM, bool TRANS, bool ACTA, class LoadA>
 __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, float* Ws, const WSpec w, LoadA loadA, int actA = CFFM_ACT_RELU) {
     constexpr int BN = NT * 16;
     constexpr int NREC = 4 * BN;                       // (kk, column) double records of one 32-deep step: 8 k each
@@ -218,7 +222,6 @@ __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kk = lane >> 4;
     const int nks = (khalves + 1) >> 1;
     u32x4_t* Wl = reinterpret_cast<u32x4_t*>(Ws);
-    float4 areg[RM][2], anext[RM][2];
     // The weight tile is split ONCE per launch (pack_w_b3_kernel, w.pre) into the very records this loop reads,
     // [k-step][piece][kk][padded column]: a step's tile is 12 rows of BN records = 24 wave-sized pieces that go global -> LDS by
     // DMA (global_load_lds_dwordx4, six per wave) - no staging registers, no split instructions, no ds_write in the loop.
@@ -233,26 +236,32 @@ __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, 
                                              (void __attribute__((address_space(3)))*)(buf + row * BN + half * 64), 16, 0, 0);
         }
     };
-    loadA(0, areg);
-    __syncthreads();                          // previous users of Ws are done
-    dmaW(0, Wl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int ks = 0; ks < nks; ++ks) {
-        const bool more = ks + 1 < nks;
-        if (more) {
-            loadA(ks + 1, anext);
-            dmaW(ks + 1, Wl + ((ks + 1) & 1) * PBUF);              // that buffer was last read in step ks - 1, behind a barrier
-        }
-        if (actA != CFFM_ACT_RELU && actA != CFFM_ACT_PRELU && actA != CFFM_ACT_ELU) {
+    // A operands are requested TWO steps ahead: a step of this loop is 1536 MFMA cycles per wave (the fp32 loop: 4096), too short
+    // to cover an HBM round trip under load with one step of lookahead.  It costs no register: the raw float4s of a step are dead
+    // once they are split into bf16 pieces at the top of the step, so the loads of step ks + 2 go into the registers step ks just
+    // gave up (two register sets, the loop runs in pairs of steps).  The filter tile comes out of L2 / MALL and stays one step ahead;
+    // it is requested BEFORE the A loads, so that "at most RM * 2 loads still in flight" (vmcnt) means "the DMA has landed".
+    float4 aA[RM][2], aB[RM][2];
+    // FULL = true: a step of the main loop, both lookaheads exist - no branch in it, so that hipcc's own wait for `cur` at the top
+    // of the next step counts the RM * 2 younger loads exactly (vmcnt(RM * 2)) instead of falling back to vmcnt(0) where control
+    // flow merges
+    auto body = [&](int ks, float4 (&cur)[RM][2], auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const bool more = FULL || ks + 1 < nks, more2 = FULL || ks + 2 < nks;
+        if constexpr (ACTA) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int rm = 0; rm < RM; ++rm) act_pos4(areg[rm][h], actA);
+                for (int rm = 0; rm < RM; ++rm) act_pos4(cur[rm][h], actA);
         }
         u32x4_t ap[RM][3];
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm) split8_bf16x3(areg[rm][0], areg[rm][1], ap[rm]);
+        for (int rm = 0; rm < RM; ++rm) split8_bf16x3(cur[rm][0], cur[rm][1], ap[rm]);
+        __builtin_amdgcn_sched_barrier(0);                         // the splits read `cur` before the loads below overwrite it
+        if (more) dmaW(ks + 1, Wl + ((ks + 1) & 1) * PBUF);        // that buffer was last read in step ks - 1, behind a barrier
+        __builtin_amdgcn_sched_barrier(0);                         // DMA first, A loads second: see the vmcnt below
+        if (more2) loadA(ks + 2, cur);
+        __builtin_amdgcn_sched_barrier(0);
         // (an odd last step: the B records of its second half are zeros - the image is zero beyond k_lim - and the A values
         //  there are finite numbers read from a clamped address)
         const u32x4_t* Wb = Wl + (ks & 1) * PBUF + kk * BN + r;
@@ -274,12 +283,31 @@ __device__ __forceinline__ void gemm_tile_b3(f32x4 (&acc)[RM][NT], int khalves, 
 #pragma unroll
                     for (int rm = 0; rm < RM; ++rm) acc[rm][nt + u] = mfma_bf16(ap[rm][TA[t]], b[u][TB[t]], acc[rm][nt + u]);
         }
-        if (more) {
-#pragma unroll
-            for (int rm = 0; rm < RM; ++rm) { areg[rm][0] = anext[rm][0]; areg[rm][1] = anext[rm][1]; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the next tile have landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {                                                // this wave's pieces of the next tile have landed; the A loads of
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RM * 2) : "memory");   // step ks + 2 (issued after them) may stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        // A bare s_barrier: __syncthreads() and lds_barrier() both make hipcc wait for EVERY vector-memory operation in flight
+        // (vmcnt(0): it counts the LDS DMA as a write to the fenced address space), which would take the second step of lookahead
+        // away again.  What the barrier has to order is covered explicitly: this wave's DMA pieces by the vmcnt above, its LDS reads
+        // of the current tile by the MFMAs that consumed them.
+        asm volatile("s_barrier" ::: "memory");
+    };
+    loadA(0, aA);
+    __syncthreads();                          // previous users of Ws are done
+    dmaW(0, Wl);
+    if (nks > 1) loadA(1, aB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 3 < nks; ks += 2) {
+        body(ks, aA, std::true_type());
+        body(ks + 1, aB, std::true_type());
+    }
+    for (; ks < nks; ks += 2) {               // the last two to three steps
+        body(ks, aA, std::false_type());
+        if (ks + 1 < nks) body(ks + 1, aB, std::false_type());
     }
 }
 
@@ -436,7 +464,10 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (B3) gemm_tile_b3<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, a.act);
+    if constexpr (B3) {
+        if (a.act != CFFM_ACT_RELU && a.act != CFFM_ACT_PRELU && a.act != CFFM_ACT_ELU) gemm_tile_b3<NT, RM, false, true>(acc, 4 * Pp / 16, Ws, wspec, loadA, a.act);
+        else gemm_tile_b3<NT, RM, false, false>(acc, 4 * Pp / 16, Ws, wspec, loadA);
+    }
     else gemm_tile<NT, RM, false>(acc, 4 * Pp / 16, Ws, wspec, loadA, GEN ? CFFM_ACT_RELU : a.act);   // act(C_{l-1}) on the A operand
 
     float psum[RM][4];                                         // pool partials: this lane's column of every row it holds
@@ -591,7 +622,7 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
             for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[rm][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (B3) gemm_tile_b3<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
+            if constexpr (B3) gemm_tile_b3<NT, RM, true, false>(acc, Pp / 16, Ws, wspec, loadA);
             else gemm_tile<NT, RM, true>(acc, Pp / 16, Ws, wspec, loadA);
 
             // ---- epilogue ------------------------------------------------------------------------
