@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
         a_off = tap < 4 ? ((tap >> 1) * Sin + (tap & 1)) * Pp + p : -1;
     }
     const int qcol = q0 + 4 * c4;                                     // dC: first channel of the block
+    const int rbase = (r & 3) * 32 + (r >> 2);                         // MFMA lane r reads channel 16 x + r at record rbase + 4 (x ^ (r & 3))
     f32x4 acc[RI][NT];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri)
@@ -1168,8 +1169,14 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) { bsum[0] += reg[t].x; bsum[1] += reg[t].y; bsum[2] += reg[t].z; bsum[3] += reg[t].w; }
         }
-        u32x4_t* dst = stA ? As + oct * BI + 4 * c4 : Bs + oct * BQ + 4 * c4;
-        const int pstride = stA ? NO * BI : NO * BQ;
+        // Row image (BI or BQ records): channel (c4, ch) = 4 c4 + ch sits at record ch * 32 + (c4 ^ (ch << 2)).  Written as it comes -
+        // a thread's four channels side by side - the 16-byte stores of consecutive lanes lie 64 bytes apart: 57 % of the LDS
+        // cycles of this kernel were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r04_syn1m_pmc_*).  In this
+        // image store ch of lanes c4 = 0 .. 31 is a permutation of one contiguous 512-byte plane, and the read of 16 consecutive
+        // channels (lane r: ch = r & 3, c4 = 4 x + (r >> 2)) touches the sixteen 4-bank groups 16 (r & 3 ^ x & 3) + 4 (r >> 2) once each.
+        static_assert(BI == 128 && BQ == 128, "four channel planes of 32 records");
+        u32x4_t* dst = (stA ? As : Bs) + oct * 128;
+        const int pstride = NO * 128;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             float v[8];
@@ -1177,7 +1184,8 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
             for (int t = 0; t < 8; ++t) v[t] = ch == 0 ? reg[t].x : ch == 1 ? reg[t].y : ch == 2 ? reg[t].z : reg[t].w;
             u32x4_t p[3];
             split8_bf16x3(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p);
-            if (stOn) { dst[ch] = p[0]; dst[pstride + ch] = p[1]; dst[2 * pstride + ch] = p[2]; }
+            const int pos = ch * 32 + (c4 ^ (ch << 2));
+            if (stOn) { dst[pos] = p[0]; dst[pstride + pos] = p[1]; dst[2 * pstride + pos] = p[2]; }
         }
     };
 
@@ -1192,7 +1200,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) af[ri][pc] = As[(pc * NO + kk) * BI + (wave * RI + ri) * 16 + r];
+            for (int pc = 0; pc < 3; ++pc) af[ri][pc] = As[(pc * NO + kk) * 128 + rbase + 4 * ((wave * RI + ri) ^ (r & 3))];
         static_assert(NT % 2 == 0, "column tiles are taken in pairs");
 #pragma unroll
         for (int nt = 0; nt < NT; nt += 2) {
@@ -1200,7 +1208,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) bf[u][pc] = Bs[(pc * NO + kk) * BQ + (nt + u) * 16 + r];
+                for (int pc = 0; pc < 3; ++pc) bf[u][pc] = Bs[(pc * NO + kk) * 128 + rbase + 4 * ((nt + u) ^ (r & 3))];
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // the small terms first
 #pragma unroll
             for (int t = 0; t < 6; ++t)
