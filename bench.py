@@ -205,6 +205,10 @@ def stress_step(eng, cfg, ids, B):
     return {'workload': WORKLOADS['syn1m']['text'], 'steps': 3, 'warmup': 1, 'ms_per_step': round(ms, 2),
             'examples_per_s': round(B / (ms * 1e-3), 1), 'executed_TFLOPs': round(ex_tf, 1),
             'executed_frac_of_mfma_f32_peak': round(ex_tf / MFMA_F32_PEAK_TFLOPS, 4),
+            'contraction': 'fp32 MFMA loops (CFFM_CONV_FP32=1)' if os.environ.get('CFFM_CONV_FP32') else
+                           'direct conv layers on the bf16 MFMA pipe at fp32 accuracy (error-free 3-way bf16 split of both operands, six '
+                           'cross terms, fp32 accumulate; DESIGN.md 3.4): executed_TFLOPs is the fp32-EQUIVALENT rate; layer 0 (rank-1 '
+                           'factorised) on fp32 MFMAs',
             'reference_algorithm_TFLOPs': round(ref_tf, 1), 'loss': round(loss, 6),
             'note': 'executed = conv layer 0 factorised (rank-1 input channels), layers >= 1 direct, 3 contractions per layer, '
                     'unpadded; peak = 157.3 TFLOP/s dense fp32 MFMA'}

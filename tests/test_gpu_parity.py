@@ -48,6 +48,12 @@ CASES = {
     # one: its generic-activation build (selu) and its relu build
     'f32-k64-d64-b11-selu': dict(M=3000, F=32, K=64, D=64, act='selu', B=11),
     'f32-k64-d64-b9-relu': dict(M=3000, F=32, K=64, D=64, act='relu', B=9),
+    # the bf16x3 instances of the direct conv layers (round 4: forward / input gradient of a layer with >= 32768 rows at NT = 8, the
+    # weight gradient at any row count) with an activation that is NOT the identity on the stored relu output: selu goes through
+    # the A-operand activation of gemm_tile_b3 / wgrad3's staging.  (gelu at this batch size fails on the top layer's dC under BOTH
+    # conv loops - 50 of 262144 elements where relu(z) sits just outside the band adopt_device_kinks covers and gelu'(0+) = 0.5 makes
+    # the decision an O(1) change - so the gelu arm is covered by the small gelu cases only.)
+    'f16-k8-d32-b512-selu': dict(M=4000, F=16, K=8, D=32, act='selu', B=512, heavy=True),
     # more than 4,096 lookups per step: the rocPRIM radix sort + segment walk of the sparse update (the CLI's default
     # --batch_size 1024), with heavy duplication (ids drawn from 150 values per column)
     'frappe-b1024-dups': dict(M=5382, F=10, K=32, D=32, act='selu', B=1024, id_range=150),

@@ -18,10 +18,10 @@ python3 bench.py --workload syn1m --steps 3 --warmup 1 --quick > gpurun_out/${ta
 for d in ${tag}_kt_frappe ${tag}_kt_syn1m; do python3 tools/stats_md.py gpurun_out/$d "$d" > gpurun_out/$d.md 2>&1; done
 for d in ${tag}_pmcA ${tag}_pmcB; do python3 tools/pmc_report.py gpurun_out/$d > gpurun_out/$d.txt 2>&1; done
 # the wide parity cases under both conv loops
-K='f32 or f16-d32 or f20 or f33'
-python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "$K" > gpurun_out/${tag}_par_b3.log 2>&1; tail -1 gpurun_out/${tag}_par_b3.log
+K='f32 or f16-d32 or f16-k8 or f20 or f33 or cfg4'
+python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q -k "$K" > gpurun_out/${tag}_par_b3.log 2>&1; tail -1 gpurun_out/${tag}_par_b3.log
 cp gpurun_out/parity_worst.json gpurun_out/${tag}_parity_worst_b3.json
-CFFM_CONV_FP32=1 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "$K" > gpurun_out/${tag}_par_fp32.log 2>&1; tail -1 gpurun_out/${tag}_par_fp32.log
+CFFM_CONV_FP32=1 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q -k "$K" > gpurun_out/${tag}_par_fp32.log 2>&1; tail -1 gpurun_out/${tag}_par_fp32.log
 cp gpurun_out/parity_worst.json gpurun_out/${tag}_parity_worst_fp32.json
 find gpurun_out/${tag}_* -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null
 du -sh gpurun_out/${tag}_* | tail -12
