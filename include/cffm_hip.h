@@ -167,7 +167,10 @@ int cffm_outer_conv0_fwd(const cffm_shape_t *s, const float *theta, void *ws, in
 /* ws.dC[0], ws.dt1, ws.Eo -> ws.dEo, gpart slabs of conv_w[0]/conv_b[0] */
 int cffm_outer_conv0_bwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, void *stream);
 
-/* conv layer l >= 1 (CFFM.py:385-387): ws.C[l-1] -> ws.C[l] (wide: + ws.pool[l], and the relu mask of C[l] for l <= live-2) */
+/* conv layer l >= 1 (CFFM.py:385-387): ws.C[l-1] -> ws.C[l] (wide: + ws.pool[l], and the relu mask of C[l] for l <= live-2).
+ * Wide shapes (128-channel tiles, >= 32768 rows) contract on the bf16 MFMA pipe at fp32 accuracy (error-free 3-way bf16 split of both
+ * operands, six cross terms, fp32 accumulate; ws.wb3 is their scratch); the environment variable CFFM_CONV_FP32=1 selects the fp32 MFMA
+ * loops.  The same holds for cffm_conv_bwd (input gradient; its weight gradient at any row count). */
 int cffm_conv_fwd(const cffm_shape_t *s, const float *theta, void *ws, int32_t B, int32_t layer, void *stream);
 /* ws.dC[l], ws.C[l-1], ws.dt1 -> ws.dC[l-1], gpart slabs of conv_w[l]/conv_b[l].  Wide shapes: the input gradient takes the
  * relu mask of C[l-1] from ws.relu0 (see the stage contract above); the weight gradient still reads ws.C[l-1]. */
