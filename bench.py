@@ -91,8 +91,10 @@ def measured_peaks(device):
     out = torch.zeros(4, device=device)
     flops = C.c_int64(0)
     ms = event_time_ms(lambda: hip.check(lib.cffm_probe_mfma(C.c_void_p(out.data_ptr()), 20000, C.byref(flops), st)), 5)
-    return {'hbm_copy_GBs': round(copy_gbs, 1), 'hbm_read_GBs': round(read_gbs, 1),
-            'mfma_f32_TFLOPs': round(flops.value / (ms * 1e-3) / 1e12, 1)}
+    f32_tf = flops.value / (ms * 1e-3) / 1e12
+    ms = event_time_ms(lambda: hip.check(lib.cffm_probe_mfma_bf16(C.c_void_p(out.data_ptr()), 20000, C.byref(flops), st)), 5)
+    return {'hbm_copy_GBs': round(copy_gbs, 1), 'hbm_read_GBs': round(read_gbs, 1), 'mfma_f32_TFLOPs': round(f32_tf, 1),
+            'mfma_bf16_TFLOPs': round(flops.value / (ms * 1e-3) / 1e12, 1)}
 
 
 def event_time_ms(fn, iters, warm=3):

@@ -73,3 +73,32 @@ extern "C" int cffm_probe_mfma(float* out, int32_t iters, int64_t* flops, void* 
     if (flops) *flops = (int64_t)blocks * 4 * iters * 8 * (2ll * 16 * 16 * 4);
     return 0;
 }
+
+// the same probe on the bf16 pipe: 8 independent v_mfma_f32_16x16x32_bf16 accumulators per wave (2 * 16 * 16 * 32 = 16384 flop each):
+// what the bf16x3 conv loops (conv.hip) are priced against - the data sheet says 2.5 PFLOP/s dense
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned probe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(float* __restrict__ out, int iters) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned w = 0x3f803f80u + (threadIdx.x & 7);                 // (1.0, 1.0) in bf16, a few low bits varied
+    const probe_u32x4 av = {w, w, w, w}, bv = {w ^ 1u, w, w ^ 2u, w};
+    const probe_bf16x8 a = __builtin_bit_cast(probe_bf16x8, av), b = __builtin_bit_cast(probe_bf16x8, bv);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    f32x4 s = acc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += acc[k];
+    if (s.x + s.y + s.z + s.w == -1.f) out[0] = s.x;        // never true: keeps the loop alive
+}
+extern "C" int cffm_probe_mfma_bf16(float* out, int32_t iters, int64_t* flops, void* stream) {
+    if (iters <= 0 || !out) return CFFM_ERR_BAD_SHAPE;
+    const int blocks = 256 * 8;
+    hipLaunchKernelGGL(probe_mfma_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, (int)iters);
+    CFFM_CHECK_LAUNCH();
+    if (flops) *flops = (int64_t)blocks * 4 * iters * 8 * (2ll * 16 * 16 * 32);
+    return 0;
+}

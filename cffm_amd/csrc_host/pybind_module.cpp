@@ -82,4 +82,5 @@ PYBIND11_MODULE(_cffm_pybind, m) {
     CFFM_BIND(cffm_probe_copy);
     CFFM_BIND(cffm_probe_read);
     CFFM_BIND(cffm_probe_mfma);
+    CFFM_BIND(cffm_probe_mfma_bf16);
 }

@@ -105,6 +105,7 @@ PROTOTYPES = {
     'cffm_probe_copy': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_read': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cffm_probe_mfma': (C.c_int, [_P, C.c_int32, _P, _P]),
+    'cffm_probe_mfma_bf16': (C.c_int, [_P, C.c_int32, _P, _P]),
     'cffm_train_step_opt': (C.c_int, [_SH, _TB, _TB, _TB, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     'cffm_train_step': (C.c_int, [_SH, _TB, _TB, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
 }

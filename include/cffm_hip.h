@@ -304,6 +304,8 @@ int cffm_probe_copy(const void *src, void *dst, int64_t bytes, void *stream);
 int cffm_probe_read(const void *src, void *sink, int64_t bytes, void *stream);
 /* dependency-free fp32 MFMA loop over the whole chip; *flops receives the flop count of the launch */
 int cffm_probe_mfma(float *out, int32_t iters, int64_t *flops, void *stream);
+/* the same on the bf16 pipe (v_mfma_f32_16x16x32_bf16): the denominator of the bf16x3 conv loops */
+int cffm_probe_mfma_bf16(float *out, int32_t iters, int64_t *flops, void *stream);
 
 /* The same step for the other optimizers of CFFM.py:517-529 (s->optimizer): state1 = Momentum accumulators / Adam m,
  * state2 = Adam v (NULL otherwise), step = 1-based Adam time step.  Adagrad routes to cffm_train_step(state1). */
