@@ -1139,8 +1139,36 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     float4 reg[8];
 
+    // The eight rows of an octet are consecutive m (m0 a multiple of 8).  Where an octet cannot straddle anything - So >= 8: same
+    // (b, y), x .. x + 7; Mtot a multiple of 8: all of it inside or all of it outside - its eight addresses are ONE base + t * pitch
+    // and its validity one flag per thread (the per-row form costs a 64-bit position and a clamp per row: ~200 of the ~800
+    // VALU instructions a staging wavefront ran per step, next to 96 MFMAs).
+    const bool octA = a.lgSo >= 3, octB = (a.Mtot & 7) == 0;
     auto fetch = [&](int64_t st) {            // global -> registers for step st (unconditional loads from clamped addresses)
         const int64_t mbase = st * KM + 8 * oct;
+        if (stA && octA) {
+            const bool ok = mbase < a.Mtot && a_off >= 0;
+            const RowPos rp = row_pos(mbase < a.Mtot ? mbase : 0, a.lgSo);
+            const float* src = a.in + ((((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp + (a_off >= 0 ? a_off : 0));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) reg[t] = *reinterpret_cast<const float4*>(src + (int64_t)t * 2 * Pp);
+            if (!ok) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) reg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        if (!stA && octB) {
+            const bool ok = stOn && mbase < a.Mtot && qcol < Pp;
+            const float* src = a.dC + ((mbase < a.Mtot ? mbase : 0) * Pp + (qcol < Pp ? qcol : Pp - 4));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) reg[t] = *reinterpret_cast<const float4*>(src + (int64_t)t * Pp);
+            if (!ok) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) reg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int64_t m = mbase + t;
@@ -1165,7 +1193,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) act_pos4(reg[t], a.act);                  // A' = act(C_{l-1}), C >= 0
         }
-        if (!stA) {
+        if (!stA && ib == 0) {                               // db[q] is written by the ib == 0 tiles only
 #pragma unroll
             for (int t = 0; t < 8; ++t) { bsum[0] += reg[t].x; bsum[1] += reg[t].y; bsum[2] += reg[t].z; bsum[3] += reg[t].w; }
         }
