@@ -640,6 +640,78 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
                     ndh[nt] = tap >> 1;
                     noff[nt] = ((tap >> 1) * Sin + (tap & 1)) * Pp + p;
                 }
+                if (a.relu != nullptr) {
+                    // The mask path of the wide shapes, one ROW of the tile (this lane's NT column tiles) at a time and one row AHEAD:
+                    // the row's NT mask words and its two pool-gradient values are requested together, and the requests of row i + 1
+                    // are issued BEFORE the stores of row i.  (Element by element - load the word, wait, store, load the next word -
+                    // every load waited with vmcnt(0), which on this ISA also waits for the store issued just before it: 64 exposed
+                    // memory round trips per tile and lane, profiles/r04_dgrad_epilogue.md.)  One 16-bit word per (pixel, 16 channels):
+                    // the 16 lanes of a row share it; Pp is a multiple of 16, so lane r is channel (word, r).
+                    // Addresses: everything that depends on the column tile only is wave-uniform (a group of 16 columns never straddles
+                    // a tap: Pp is a multiple of 16) and lives in scalar registers; a row's position is kept RELATIVE to the first row
+                    // of this wavefront (positions grow with m, a wavefront's 16 * RM rows span < 2^31 floats), so that an element is
+                    // (scalar base)[32-bit offset] - no 64-bit arithmetic per element, 11 registers per row in flight.
+                    int ucol[NT], uword[NT], udh[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int nb = n0 + (nt < nvalid ? nt : 0) * 16;             // a dead column tile repeats tile 0 (never stored)
+                        const int tap = nb / Pp, p0 = nb - tap * Pp;
+                        udh[nt] = __builtin_amdgcn_readfirstlane(tap >> 1);
+                        ucol[nt] = __builtin_amdgcn_readfirstlane(((tap >> 1) * Sin + (tap & 1)) * Pp + p0);
+                        uword[nt] = ucol[nt] >> 4;
+                    }
+                    int64_t m_first = m0 + wave * (16 * RM);
+                    if (m_first >= a.Mtot) m_first = a.Mtot - 1;
+                    const RowPos rf = row_pos(m_first, a.lgSo);
+                    const int64_t base_v = (((int64_t)rf.b * Sin + 2 * rf.y) * Sin + 2 * rf.x) * Pp;
+                    const int64_t base64 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(base_v >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base_v);
+                    float* dtile = a.dprev + base64;
+                    const uint16_t* wtile = a.relu + (base64 >> 4);
+                    struct RowReq { uint32_t rel; bool ok; float t0, t1v; uint32_t wm[NT]; };
+                    // INTERIOR (all NT column tiles live, all BM rows below Mtot - every tile but those of the last row / column block):
+                    // no predicate on any store, i.e. no exec-mask branch per element
+                    auto sweep = [&](auto interior) {
+                        constexpr bool IN = decltype(interior)::value;
+                        auto request = [&](int idx, RowReq& q) {
+                            const int64_t m = m0 + wave * (16 * RM) + (idx >> 2) * 16 + kk * 4 + (idx & 3);
+                            q.ok = IN || m < a.Mtot;
+                            const RowPos rp = row_pos(q.ok ? m : a.Mtot - 1, a.lgSo);
+                            q.rel = (uint32_t)((((int64_t)rp.b * Sin + 2 * rp.y) * Sin + 2 * rp.x) * Pp - base64);
+                            const float* tp = a.dt1 + (int64_t)rp.b * a.t1w + a.t1off + 2 * rp.y;
+                            q.t0 = tp[0]; q.t1v = tp[1];
+                            const uint32_t wrel = q.rel >> 4;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) q.wm[nt] = wtile[wrel + (uint32_t)uword[nt]];
+                        };
+                        auto finish = [&](int idx, const RowReq& q) {
+                            const int rm = idx >> 2, j = idx & 3;
+                            const uint32_t er = q.rel + (uint32_t)r;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                if (!IN && nt >= nvalid) continue;
+                                const float g = acc[rm][nt][j] + (udh[nt] ? q.t1v : q.t0);
+                                const float d = ((q.wm[nt] >> r) & 1u) ? gsc : 0.f;
+                                if (IN || q.ok) __builtin_nontemporal_store(g * d, dtile + (er + (uint32_t)ucol[nt]));
+                            }
+                        };
+                        RowReq qa, qb;
+                        request(0, qa);
+#pragma unroll
+                        for (int idx = 0; idx < RM * 4; idx += 2) {
+                            request(idx + 1, qb);
+                            __builtin_amdgcn_sched_barrier(0);
+                            finish(idx, qa);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (idx + 2 < RM * 4) request(idx + 2, qa);
+                            __builtin_amdgcn_sched_barrier(0);
+                            finish(idx + 1, qb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    };
+                    if (nvalid == NT && m0 + BM <= a.Mtot) sweep(std::true_type());
+                    else sweep(std::false_type());
+                } else {
 #pragma unroll
                 for (int rm = 0; rm < RM; ++rm) {
                     const int64_t mrow = m0 + wave * (16 * RM) + rm * 16 + kk * 4;
@@ -656,18 +728,13 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !L0) ? 3 : 1) void dgra
                             if (nt >= nvalid) continue;
                             const int64_t pos = rowbase + noff[nt];
                             const float g = acc[rm][nt][j] + (ndh[nt] ? t1v : t0);
-                            float d;
-                            if (a.relu != nullptr) {           // one 16-bit word per (pixel, 16 channels): the 16 lanes of a row share it
-                                const uint32_t wmask = a.relu[(pos - r) >> 4];   // (Pp is a multiple of 16: lane r is channel (word, r))
-                                d = ((wmask >> r) & 1u) ? gsc : 0.f;
-                            } else {
-                                const float c = a.Cprev[pos];
-                                d = c > 0.f ? gsc : 0.f;
-                                if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
-                            }
+                            const float c = a.Cprev[pos];
+                            float d = c > 0.f ? gsc : 0.f;
+                            if (gel) d = c > 0.f ? act_grad_f(c, CFFM_ACT_GELU) : 0.f;
                             __builtin_nontemporal_store(g * d, &a.dprev[pos]);
                         }
                     }
+                }
                 }
             }
 #pragma unroll
