@@ -476,33 +476,50 @@ __global__ __launch_bounds__(256, (NT == 8 && RM == 2 && !GEN) ? 3 : 1) void con
 #pragma unroll
         for (int j = 0; j < 4; ++j) psum[rm][j] = 0.f;
     const int pact = GEN ? CFFM_ACT_RELU : a.act;              // (the pools apply self.activation to the stored relu output, :387)
+    // The bias of every column tile is requested BEFORE the first store: a.bias and a.out may alias as far as hipcc knows, so a load
+    // that follows a store is kept behind it and waits with vmcnt(0) - for itself and for every store in front of it (16 such round
+    // trips per tile in the loop below as it was first written).
+    float bvv[NT];
 #pragma unroll
-    for (int rm = 0; rm < RM; ++rm) {
-        unsigned long long mine = 0;                           // relu mask (a.relu): lane (kk, r = 4*(nt & 3) + j) keeps the ballot of (nt, j)
+    for (int nt = 0; nt < NT; ++nt) bvv[nt] = a.bias[n0 + (nt < nvalid ? nt : 0) * 16 + r];
+    // INTERIOR: every column tile live, every row below Mtot (all tiles but those of the last row / column block) - no predicate on a
+    // store.  PLAIN: the pool activation is the identity on [0, inf) (relu / prelu / elu) - no activation switch per element.
+    // An element is (wave-uniform tile base)[32-bit offset]: no 64-bit arithmetic per element.
+    int64_t mw = m0 + wave * (16 * RM);
+    float* otile = a.out + ((int64_t)__builtin_amdgcn_readfirstlane((int)((mw * Pp) >> 32)) << 32 |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mw * Pp)));
+    const uint32_t olane = (uint32_t)(kk * 4 * Pp + n0 + r);
+    auto epilogue = [&](auto interior, auto plain) {
+        constexpr bool IN = decltype(interior)::value, PL = decltype(plain)::value;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (nt < nvalid) {
-                const int n = n0 + nt * 16 + r;
-                const float bv = a.bias[n];
+        for (int rm = 0; rm < RM; ++rm) {
+            unsigned long long mine = 0;                       // relu mask (a.relu): lane (kk, r = 4*(nt & 3) + j) keeps the ballot of (nt, j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + j;
-                    const float c = fmaxf(acc[rm][nt][j] + bv, 0.f);                       // CFFM.py:478
-                    if (m < a.Mtot) a.out[m * Pp + n] = c;
-                    psum[rm][j] += act_pos(c, a.act);              // padded channels: zero filter and bias -> act(0) = 0
-                    if (!GEN) {
-                        const unsigned long long bal = __ballot(c > 0.f);   // bits 16kk..16kk+15: the 16 channels of row (kk, j)
-                        if (r == 4 * (nt & 3) + j) mine = bal;
+            for (int nt = 0; nt < NT; ++nt) {
+                if (IN || nt < nvalid) {
+                    const float bv = bvv[nt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c = fmaxf(acc[rm][nt][j] + bv, 0.f);                   // CFFM.py:478
+                        if (IN || mw + rm * 16 + kk * 4 + j < a.Mtot) otile[olane + (uint32_t)((rm * 16 + j) * Pp + nt * 16)] = c;
+                        psum[rm][j] += PL ? c : act_pos(c, a.act);     // padded channels: zero filter and bias -> act(0) = 0
+                        if (!GEN) {
+                            const unsigned long long bal = __ballot(c > 0.f);   // bits 16kk..16kk+15: the 16 channels of row (kk, j)
+                            if (r == 4 * (nt & 3) + j) mine = bal;
+                        }
                     }
                 }
-            }
-            if (!GEN && a.relu != nullptr && ((nt & 3) == 3 || nt == NT - 1)) {   // four column tiles collected: one 2-byte store per lane
-                const int ntw = (nt & ~3) + (r >> 2);
-                const int64_t m = m0 + wave * (16 * RM) + rm * 16 + kk * 4 + (r & 3);
-                if (ntw <= nt && ntw < nvalid && m < a.Mtot) a.relu[m * (Pp >> 4) + (n0 >> 4) + ntw] = (uint16_t)(mine >> (16 * kk));
+                if (!GEN && a.relu != nullptr && ((nt & 3) == 3 || nt == NT - 1)) {   // four column tiles collected: one 2-byte store per lane
+                    const int ntw = (nt & ~3) + (r >> 2);
+                    const int64_t m = mw + rm * 16 + kk * 4 + (r & 3);
+                    if (ntw <= nt && (IN || (ntw < nvalid && m < a.Mtot))) a.relu[m * (Pp >> 4) + (n0 >> 4) + ntw] = (uint16_t)(mine >> (16 * kk));
+                }
             }
         }
-    }
+    };
+    const bool plain_act = GEN || (a.act != CFFM_ACT_SELU && a.act != CFFM_ACT_GELU);
+    if (nvalid == NT && m0 + BM <= a.Mtot && plain_act) epilogue(std::true_type(), std::true_type());
+    else epilogue(std::false_type(), std::false_type());
     (void)pact;
     if (a.pool != nullptr) {
         // s_{l+1}[b][y] partial of this column block: columns over the 16 lanes of a DPP row, then the So rows (x) of one y in
