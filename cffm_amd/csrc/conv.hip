@@ -1395,8 +1395,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
                                                    const float* inL = nullptr, float* outL = nullptr, int64_t m_base = 0) {
     const int act = ACTC >= 0 ? ACTC : a.act;           // ACTC >= 0: compile-time activation id (README shapes)
     constexpr int PP = NT * 16, LDW = PP + 4, BM = 16 * RM;
-    constexpr int NW4 = PP * PP / 4 / 64;                     // float4 pieces of W[tap] per lane
-    float* Wl = reinterpret_cast<float*>(smem);                // [4][PP][LDW]; reused as the reduction buffer
+    float* Wl = reinterpret_cast<float*>(smem);                // [4][PP/4 row groups][4*PP + 16]; reused as the reduction buffer
     uint32_t* lut = reinterpret_cast<uint32_t*>(Wl + 4 * PP * LDW);      // [PP]            (GEN)
     float* Es = reinterpret_cast<float*>(lut + PP);           // [n_ex][F][Dp]   (GEN)
     const int tid = threadIdx.x, lane = tid & 63, tap = (tid >> 6) & 3, grp = tid >> 8, r = lane & 15, kk = lane >> 4;
@@ -1407,13 +1406,24 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
 
     PHASE_MARK2(0);
     // ---- issue every global load of this wave ----------------------------------------------------------
-    constexpr int NWG = (NW4 + G - 1) / G;                    // this wave's share of the pieces of W[tap]: i = grp + G*ii
-    float4 wv[NWG];
-    const float4* wsrc = reinterpret_cast<const float4*>(a.W + tap * PP * PP);
+    // W[tap] goes L2 -> LDS directly (global_load_lds_dwordx4), one instruction per group of four filter rows: 4 * PP floats =
+    // 16 * NT lanes of 16 bytes, contiguous on both sides.  The LDS image keeps its 2-way-at-worst bank pattern with 16 floats
+    // of padding BEHIND EVERY GROUP (row k at k * PP + (k >> 2) * 16: the four row groups kk of a fragment read lie 4 * PP + 16
+    // floats apart, 16 banks) instead of 4 floats behind every row - same size, PP * LDW per tap.  Through registers
+    // (load all, then store all) hipcc, out of registers in the fused forward, sank every load down to its LDS store: load,
+    // s_waitcnt vmcnt(0), ds_write, five times in a row - five L2 round trips per layer and example (ISA of fwd_all_kernel).
+    constexpr int NGRP = PP / 4, GSTR = 4 * PP + 16;          // row groups per tap, floats between groups
+    static_assert(NGRP * GSTR == PP * LDW, "the grouped image fills the padded one exactly");
+    float* Wt = Wl + tap * (PP * LDW);
+    // the bias of this thread's output elements (used after the cross-tap reduction): requested now, so that nothing is left to
+    // wait for between the stores of the epilogue
+    constexpr int RT = RM * G;                                 // row tiles of the workgroup
+    constexpr int EPI = (RT * NT * 64 + 256 * G - 1) / (256 * G);
+    float bpre[EPI];
 #pragma unroll
-    for (int ii = 0; ii < NWG; ++ii) {
-        const int i = grp + G * ii;
-        wv[ii] = wsrc[lane + 64 * (i < NW4 ? i : 0)];
+    for (int it = 0; it < EPI; ++it) {
+        const int idx = tid + it * 256 * G, tile = idx >> 6;
+        bpre[it] = a.bias[(tile % NT) * 16 + (idx & 15)];       // (tile % NT < NT also for idx beyond the last tile)
     }
     float4 av[RM][NT];
     if (!GEN && work) {
@@ -1433,14 +1443,18 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
         build_pair_lut(lut, a.F, PP);
         stage_examples(Es, a.in, b0, n_ex, a.B, a.F, a.D, Dp);
     }
-    // ---- W[tap] -> this wave's LDS quarter ------------------------------------------------------------------
-    float* Wt = Wl + tap * (PP * LDW);
+    // (the DMA is requested BEHIND the A operands / the staging above: hipcc waits with vmcnt(0) in front of any LDS access that
+    //  follows a global_load_lds, and in the fused forward the A operands are LDS reads)
+    {
+        const float4* wsrc = reinterpret_cast<const float4*>(a.W + tap * PP * PP);
+        if (lane < 16 * NT) {
 #pragma unroll
-    for (int ii = 0; ii < NWG; ++ii) {
-        const int i = grp + G * ii;
-        const int u = lane + 64 * i, row = u / (PP / 4), c4 = u % (PP / 4);
-        if (i < NW4) *reinterpret_cast<float4*>(&Wt[row * LDW + 4 * c4]) = wv[ii];
+            for (int gI = grp; gI < NGRP; gI += G)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + gI * (16 * NT) + lane),
+                                                 (void __attribute__((address_space(3)))*)(Wt + gI * GSTR), 16, 0, 0);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's filter rows have landed (and its A operands, and the bias)
     lds_barrier();
     PHASE_MARK2(1);
     if (!work) {
@@ -1485,7 +1499,7 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
             const int krow = 16 * h + 4 * kk + t;
             float bf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = Wt[krow * LDW + nt * 16 + r];
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = Wt[krow * PP + (krow >> 2) * 16 + nt * 16 + r];
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) {
                 const float x = t == 0 ? av[rm][h].x : t == 1 ? av[rm][h].y : t == 2 ? av[rm][h].z : av[rm][h].w;
@@ -1498,21 +1512,23 @@ __device__ __forceinline__ void conv_fwd_taps_body(const ConvArgs& a, int64_t m0
     PHASE_MARK2(3);
     lds_barrier();                                           // every wave is done with its W quarter
     PHASE_MARK2(4);
-    constexpr int RT = RM * G;                                 // row tiles of the workgroup
     f32x4* red = reinterpret_cast<f32x4*>(Wl);                 // [4 taps][RT*NT tiles][64 lanes]
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[(tap * RT * NT + (grp * RM + rm) * NT + nt) * 64 + lane] = acc[rm][nt];
     lds_barrier();
-    for (int idx = tid; idx < RT * NT * 64; idx += 256 * G) {
+#pragma unroll
+    for (int it = 0; it < EPI; ++it) {
+        const int idx = tid + it * 256 * G;
+        if (idx >= RT * NT * 64) break;
         const int tile = idx >> 6, ln = idx & 63, rm = tile / NT, nt = tile - rm * NT;
         f32x4 v = red[idx];
         v += red[RT * NT * 64 + idx];
         v += red[2 * RT * NT * 64 + idx];
         v += red[3 * RT * NT * 64 + idx];
         const int n = nt * 16 + (ln & 15);
-        const float bv = a.bias[n];
+        const float bv = bpre[it];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0_wg + rm * 16 + (ln >> 4) * 4 + j;
