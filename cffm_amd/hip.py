@@ -15,7 +15,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('CFFM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcffm_hip.so')   # CFFM_HIP_LIB: another build of the library (A/B timing of kernel variants)
+# CFFM_HIP_LIB: another build of the library for the ctypes handle.  NOT enough for A/B timing of kernel variants: fast() calls go through
+# _cffm_pybind, which binds to the libcffm_hip.so next to it (RUNPATH $ORIGIN) - point CFFM_HOST_LIB_DIR at a directory that holds the
+# other library AND a pybind11 module linked against it (tools/experiments/ab_old_new.sh checks /proc/self/maps for exactly this).
+LIB_PATH = os.environ.get('CFFM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcffm_hip.so')
 
 ABI_VERSION = 9
 MAX_LAYERS = 8
