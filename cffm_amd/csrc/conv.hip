@@ -2565,17 +2565,9 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, int slab, in
             }
             __syncthreads();
             PHASE_MARKB(33, dbgw);
-            // (the A' values are made opaque here: hipcc otherwise hoists the activation of the MFMA loop below - a multiply by the selu
-            //  scale - up into the four load blocks above, and each block then ends in a wait for its own loads: four L2 round trips
-            //  in a row instead of 48 loads in flight behind the staging of dC)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (g * UNR < nk) {
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                        for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(av[g][u][i]));
-                }
+            // (tried and taken out again, DESIGN 3.5 #5: making the A' values opaque here keeps hipcc from hoisting the selu multiply of the
+            //  loop below into the four load blocks above - 48 loads in flight in the ISA instead of 4 x 12 with a wait each - and
+            //  conv01_bwd_kernel ran 0.40 us SLOWER with it, same box, 2 x 330 launches: profiles/r04_ab_old_new_trace_same_box.txt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (g * UNR < nk) {
