@@ -3,6 +3,12 @@
 # round-4 changes of DESIGN 3.5) linked with HEAD's other objects, cffm_amd/lib/ = HEAD.  Each leg goes through its OWN pybind11
 # module and ABORTS unless the libcffm_hip image it mapped is the one it is meant to time (CFFM_HIP_LIB alone is not enough: the
 # pybind11 module binds to the library next to it).
+# Recipe for the other library (here, not on the box):
+#   git show <commit>:cffm_amd/csrc/conv.hip > cffm_amd/csrc/conv_old.hip      # must sit in csrc/: common.hpp includes ../../include
+#   hipcc <CXXFLAGS of the Makefile> -c cffm_amd/csrc/conv_old.hip -o build/ab/conv_old.o && rm cffm_amd/csrc/conv_old.hip
+#   hipcc -shared -fPIC --offload-arch=gfx950 $(ls build/*.o | grep -v '^build/conv.o$') build/ab/conv_old.o -o tools/experiments/ab_lib/libcffm_hip.so
+#   g++ ... pybind_module.cpp -o tools/experiments/ab_lib/_cffm_pybind$(python3-config --extension-suffix) -Ltools/experiments/ab_lib -lcffm_hip -Wl,-rpath,'$ORIGIN'
+#   cp cffm_amd/lib/libcffm_libfm.so tools/experiments/ab_lib/       (build/ is NOT sent to the GPU box; tools/experiments/ab_lib/*.so is, and is git-ignored)
 set -u
 R=$GRAFT_REPO_ROOT
 leg() { # tag, expected library path fragment, forbidden fragment, env...
