@@ -4,6 +4,13 @@ barriers and MFMA runs in program order (line numbers inside the kernel).  What 
 not show - a load that hipcc sank next to its use (load, vmcnt(0), use, load, ...), a vmcnt(0) inside a predicated store block
 (which also waits for the store in front of it), spills on the critical path.
 
+LIMITS (learned the hard way): this is the STATIC code.  (1) It lists branches the workload never takes - the four
+"load x3, wait, store x5" blocks of conv01_bwd_kernel are the `!first` side of the layer-0 slab update, dead in the fused step where a
+workgroup holds one example; the staging loop it shows in fwd_all_kernel is the non-`early` path.  Read the branch conditions before
+believing a chain is executed.  (2) A chain that is executed may still be covered by other wavefronts: of three gains predicted from
+counting round trips here, none came out as predicted and one was a loss.  Use it to find candidates; decide with
+tools/experiments/ab_old_new_trace.sh (old and new library on one box).
+
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -S --cuda-device-only cffm_amd/csrc/conv.hip -o /tmp/conv.s
     tools/isa_waits.py /tmp/conv.s fwd_all_kernelILi3ELi8ELi3E [first_line last_line]
 """
